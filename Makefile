@@ -1,0 +1,20 @@
+# Builds the product library (HIP, gfx950) and the CPU oracle (test infrastructure).
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+PKG     := opencl_path_tracer_amd
+CSRC    := $(PKG)/csrc
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-result
+
+all: $(PKG)/libptamd.so oracle
+
+$(PKG)/libptamd.so: $(CSRC)/pt_host.cpp $(CSRC)/pt_obj.cpp $(CSRC)/pt_kernels.hip $(CSRC)/pt_internal.hpp include/pt_api.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/pt_host.cpp $(CSRC)/pt_obj.cpp $(CSRC)/pt_kernels.hip
+
+oracle:
+	$(MAKE) -C oracle -s
+
+clean:
+	rm -f $(PKG)/libptamd.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,155 @@
+/*
+ * pt_api.h -- C ABI of the MI355X-native path-tracing hot path (libptamd.so).
+ *
+ * Drop-in boundary: the reference's host class `Scene` (main.cpp:363-742) and the value
+ * types it is fed (main.cpp:92-193, 306-348).  Every entry point below names the
+ * reference interface it replaces ("main.cpp:NN" = /root/reference/main.cpp,
+ * "prog.cl:NN" = /root/reference/prog.cl).  Call order is the reference's:
+ *
+ *   pt_create                       (Scene::init_Scene)
+ *   pt_add_material*                (Scene::add_Material)
+ *   (pt_add_triangle* pt_end_obj)*  (Scene::add_Triangle / Scene::end_Obj)   | pt_add_obj*
+ *   pt_upload_triangles             (Scene::upload_Triangles)
+ *   pt_upload_materials             (Scene::upload_Materials)
+ *   pt_render* | (pt_generate_rays pt_trace_rays)*        (Scene::render / generate_rays / trace_rays)
+ *   pt_read_colors / pt_read_rnds / pt_read_rays / pt_resolve_ldr
+ *   pt_destroy
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  Every function returns
+ * PT_OK (0) or a negative PT_E* code and never calls exit(); the message is available from
+ * pt_last_error().  Upload/add functions copy (the caller keeps ownership of its arrays);
+ * read functions fill caller-provided host buffers.  One host thread per context; one
+ * context per GPU.  Nothing here runs on the CPU as a fallback: without a usable HIP
+ * device pt_create fails with PT_ENODEVICE.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_EINVAL (-1)     /* bad argument / call order */
+#define PT_ENODEVICE (-2)  /* no HIP device, or the device is not gfx950-compatible */
+#define PT_EHIP (-3)       /* a HIP runtime call failed (text in pt_last_error) */
+#define PT_ESCENE (-4)     /* scene cannot be built (e.g. the reference's build would not terminate) */
+#define PT_EIO (-5)        /* OBJ/MTL file could not be read or parsed */
+
+/* ---- value types, byte-compatible with the reference's device structs ------------ */
+typedef struct { float s[4]; } pt_float3;                 /* cl_float3: 16 B, .s[3] is padding */
+typedef struct {                                           /* Material: prog.cl:1-5, main.cpp:92-112 (80 B) */
+    pt_float3 kd, ks, emission, F0;
+    float n, shininess;
+    int32_t type;                                          /* 0 diffuse, 1 mirror, 2 dielectric, 3 emitter */
+    int32_t _pad;
+} pt_material;
+typedef struct { pt_float3 P, D; } pt_ray;                 /* Ray: prog.cl:7-9 (32 B) */
+typedef struct {                                           /* Triangle: prog.cl:18-21, main.cpp:139-182 (80 B) */
+    pt_float3 r1, r2, r3, N;
+    uint16_t mati;
+    uint8_t _pad[14];
+} pt_triangle;
+typedef struct {                                           /* Camera: prog.cl:32-35, main.cpp:306-348 (80 B) */
+    pt_float3 eye, lookat, up, right;
+    float XM, YM;
+    float _pad[2];
+} pt_camera;
+
+typedef struct pt_context pt_context;
+
+/* ---- value-type constructors (host arithmetic of the reference's constructors) --- */
+/* Material(kd,ks,emission,N,K,shininess,type): main.cpp:101-111 */
+void pt_material_init(pt_material* m, const float kd[3], const float ks[3], const float emission[3],
+                      const float N[3], const float K[3], float shininess, int32_t type);
+/* Triangle(r1,r2,r3,mati): main.cpp:144-166 (precomputes the unit geometric normal) */
+void pt_triangle_init(pt_triangle* t, const float r1[3], const float r2[3], const float r3[3], uint16_t mati);
+/* Camera(): main.cpp:311-347, with the globals it reads (global_fov/yaw/pitch/shift,
+ * screen_width/height: main.cpp:20-21,30-39) passed as arguments */
+void pt_camera_init(pt_camera* c, float fov, float yaw, float pitch, const float shift[3],
+                    int32_t width, int32_t height);
+
+/* ---- context: Scene::init_Scene, main.cpp:456-528 --------------------------------- */
+/* Selects HIP device `device`, allocates rays (32 B/px), rnds (4 B/px), colors (16 B/px)
+ * and seeds rnds from std::minstd_rand0 in pixel order (main.cpp:508-527). */
+int pt_create(int device, int32_t width, int32_t height, pt_context** out);
+/* Multi-GPU variant: this context owns the rows r with (r / rows_per_block) % world == rank
+ * of the global width x height frame.  Seeds and pixel ids stay those of the
+ * GLOBAL frame, so the union of all ranks' pixels equals a 1-GPU render bit for bit. */
+int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int32_t world,
+                    int32_t rows_per_block, pt_context** out);
+void pt_destroy(pt_context* ctx);
+/* Message of the last failure on ctx (ctx == NULL: last failure of pt_create*). */
+const char* pt_last_error(const pt_context* ctx);
+/* Scene::list_info, main.cpp:389-455: one line describing the device into buf. */
+int pt_device_info(const pt_context* ctx, char* buf, int32_t buflen);
+
+/* ---- scene authoring: main.cpp:529-617 --------------------------------------------- */
+int pt_add_material(pt_context* ctx, const pt_material* m);          /* Scene::add_Material: returns the index (>= 0) */
+int pt_add_triangle(pt_context* ctx, const pt_triangle* t);          /* Scene::add_Triangle */
+int pt_add_triangles(pt_context* ctx, const pt_triangle* t, int64_t n); /* n x add_Triangle */
+int pt_end_obj(pt_context* ctx);                                     /* Scene::end_Obj: closes one object */
+/* Scene::add_Obj(file,pos,scale,pitch,yaw), main.cpp:552-617: OBJ+MTL import with the
+ * reference's conventions (x negated, rotate_x(pitch), rotate_y(yaw), scale, translate;
+ * first three vertices of each face; MTL keys Kd Ks Ke Ns + custom Kn Kk Tp; one object
+ * per shape). */
+int pt_add_obj(pt_context* ctx, const char* file, const float pos[3], const float scale[3],
+               float pitch, float yaw);
+int pt_upload_triangles(pt_context* ctx);                            /* Scene::upload_Triangles, main.cpp:618-630 */
+int pt_upload_materials(pt_context* ctx);                            /* Scene::upload_Materials, main.cpp:631-634 */
+
+/* ---- RNG state: main.cpp:522-527 ---------------------------------------------------- */
+int pt_seed_default(pt_context* ctx);                                /* re-seed from minstd_rand0 */
+/* seeds[] holds one int per pixel of the GLOBAL frame (n = width*height) */
+int pt_upload_seeds(pt_context* ctx, const int32_t* seeds, int64_t n);
+
+/* ---- the hot path: main.cpp:635-687 -> prog.cl:384-389, 292-381 --------------------- */
+int pt_generate_rays(pt_context* ctx, const pt_camera* cam);         /* Scene::generate_rays -> gen_ray */
+int pt_trace_rays(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t current_sample); /* Scene::trace_rays -> trace_ray */
+/* nsamples x Scene::render(): for current_sample = s0 .. s0+nsamples-1 (s0 = the context's
+ * sample counter, main.cpp:28) do generate_rays + trace_rays; the counter advances by
+ * nsamples.  Fused on the device: one launch, path state in registers. */
+int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t nsamples);
+int pt_set_current_sample(pt_context* ctx, int32_t current_sample);  /* main.cpp:1046 etc.: key events reset it to 0 */
+int pt_get_current_sample(const pt_context* ctx, int32_t* out);
+int pt_sync(pt_context* ctx);                                        /* queue.finish(), main.cpp:675 */
+
+/* ---- readback (the reference never reads back; its only output is a GL texture) ----- */
+int pt_local_pixel_count(const pt_context* ctx, int64_t* out);
+int pt_local_pixel_ids(const pt_context* ctx, int32_t* out_ids, int64_t n);  /* global pixel id of each local pixel */
+int pt_read_colors(pt_context* ctx, float* out_rgba, int64_t npix);  /* buffer_colors: float3 @ 16 B stride */
+int pt_read_rnds(pt_context* ctx, int32_t* out, int64_t npix);       /* buffer_rnds */
+int pt_read_rays(pt_context* ctx, pt_ray* out, int64_t npix);        /* buffer_rays */
+/* reinhard_tone_map + sRGB of colors (prog.cl:247-269, the value write_imagef stores at
+ * prog.cl:380); which = 0 Reinhard, 1 = filt_im (3x3 median + filmic, prog.cl:391-427). */
+int pt_resolve_ldr(pt_context* ctx, int32_t which, float* out_rgba, int64_t npix);
+
+/* ---- plumbing: device memory, streams, options, statistics --------------------------- */
+/* Use caller-owned device buffers (e.g. torch tensors) for colors (16 B/px) and rnds (4 B/px)
+ * of the LOCAL pixels; current contents are copied in.  NULL keeps the internal buffer. */
+int pt_bind_framebuffer(pt_context* ctx, void* d_colors, void* d_rnds);
+void* pt_device_colors(pt_context* ctx);
+void* pt_device_rnds(pt_context* ctx);
+int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStream_t; NULL = default stream */
+/* options: "variant" 0 = megakernel, 1 = wavefront; "block" threads per workgroup;
+ * "lds_scene" 0/1 stage BVH+triangles in LDS when they fit; "timing" 0/1 HIP-event timing */
+int pt_set_option(pt_context* ctx, const char* key, int64_t value);
+/* stats: "segments" path segments executed since the last reset, "samples", "kernel_ms"
+ * (sum of HIP-event durations of the dominant kernel), "kernel_launches", "bvh_nodes",
+ * "triangles", "lds_bytes", "reset" (write-only via pt_set_option("reset_stats",1)) */
+int pt_get_stat(pt_context* ctx, const char* key, double* out);
+
+/* ---- introspection for tests (host data; no device work) ----------------------------- */
+/* Packed BVH as uploaded: nodes (64 B each), triangle packets (48 B each), per-triangle
+ * {rank, mati} pairs, and the add-order index of every packed triangle. */
+int pt_debug_bvh_sizes(const pt_context* ctx, int64_t* nnodes, int64_t* ntris);
+int pt_debug_bvh_copy(const pt_context* ctx, float* nodes, float* tris, int32_t* meta, int32_t* orig);
+/* the reference's traversal encounter rank of each triangle, in add order */
+int pt_debug_encounter_rank(const pt_context* ctx, int32_t* out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

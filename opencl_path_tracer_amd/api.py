@@ -1,0 +1,348 @@
+"""Host-side mirror of the reference's `Scene` class (main.cpp:363-742) over the C ABI of
+libptamd.so (include/pt_api.h).  Same method names, same call order, same argument meaning:
+
+    scene = Scene(width, height)            # Scene::init_Scene
+    m = scene.add_Material(kd, ks, emission, N, K, shininess, type)
+    scene.add_Triangle(r1, r2, r3, m); ...; scene.end_Obj()
+    scene.upload_Triangles(); scene.upload_Materials()
+    scene.render()                          # generate_rays + trace_rays, current_sample++
+
+The reference keeps its parameters in globals (iterations, global_fov/yaw/pitch/shift,
+current_sample: main.cpp:27-39); here they are attributes of the Scene object.
+
+There is no CPU path: if libptamd.so is missing this module raises at import, and a Scene on a
+machine without a gfx950 device raises at construction (device=None asks for a host-only
+context that can author scenes and build the BVH but cannot render).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libptamd.so")
+
+PT_OK, PT_EINVAL, PT_ENODEVICE, PT_EHIP, PT_ESCENE, PT_EIO = 0, -1, -2, -3, -4, -5
+
+MATERIAL = np.dtype([("kd", "<f4", 4), ("ks", "<f4", 4), ("emission", "<f4", 4), ("F0", "<f4", 4),
+                     ("n", "<f4"), ("shininess", "<f4"), ("type", "<i4"), ("_pad", "<i4")])
+RAY = np.dtype([("P", "<f4", 4), ("D", "<f4", 4)])
+TRIANGLE = np.dtype([("r1", "<f4", 4), ("r2", "<f4", 4), ("r3", "<f4", 4), ("N", "<f4", 4),
+                     ("mati", "<u2"), ("_pad", "u1", 14)])
+CAMERA = np.dtype([("eye", "<f4", 4), ("lookat", "<f4", 4), ("up", "<f4", 4), ("right", "<f4", 4),
+                   ("XM", "<f4"), ("YM", "<f4"), ("_pad", "<f4", 2)])
+assert MATERIAL.itemsize == 80 and RAY.itemsize == 32 and TRIANGLE.itemsize == 80 and CAMERA.itemsize == 80
+
+# every symbol include/pt_api.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "pt_material_init", "pt_triangle_init", "pt_camera_init", "pt_create", "pt_create_tiled", "pt_destroy",
+    "pt_last_error", "pt_device_info", "pt_add_material", "pt_add_triangle", "pt_add_triangles", "pt_end_obj",
+    "pt_add_obj", "pt_upload_triangles", "pt_upload_materials", "pt_seed_default", "pt_upload_seeds",
+    "pt_generate_rays", "pt_trace_rays", "pt_render", "pt_set_current_sample", "pt_get_current_sample", "pt_sync",
+    "pt_local_pixel_count", "pt_local_pixel_ids", "pt_read_colors", "pt_read_rnds", "pt_read_rays",
+    "pt_resolve_ldr", "pt_bind_framebuffer", "pt_device_colors", "pt_device_rnds", "pt_set_stream",
+    "pt_set_option", "pt_get_stat", "pt_debug_bvh_sizes", "pt_debug_bvh_copy", "pt_debug_encounter_rank",
+]
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libptamd: %s (code %d)" % (msg, code))
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError("libptamd.so is not built (run `make` or __graft_entry__.build()); "
+                          "there is no fallback implementation")
+    L = C.CDLL(_LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    fp = C.POINTER(C.c_float)
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("pt_material_init", None, vp, fp, fp, fp, fp, fp, f32, i32)
+    sig("pt_triangle_init", None, vp, fp, fp, fp, C.c_uint16)
+    sig("pt_camera_init", None, vp, f32, f32, f32, fp, i32, i32)
+    sig("pt_create", C.c_int, C.c_int, i32, i32, C.POINTER(vp))
+    sig("pt_create_tiled", C.c_int, C.c_int, i32, i32, i32, i32, i32, C.POINTER(vp))
+    sig("pt_destroy", None, vp)
+    sig("pt_last_error", C.c_char_p, vp)
+    sig("pt_device_info", C.c_int, vp, C.c_char_p, i32)
+    sig("pt_add_material", C.c_int, vp, vp)
+    sig("pt_add_triangle", C.c_int, vp, vp)
+    sig("pt_add_triangles", C.c_int, vp, vp, i64)
+    sig("pt_end_obj", C.c_int, vp)
+    sig("pt_add_obj", C.c_int, vp, C.c_char_p, fp, fp, f32, f32)
+    sig("pt_upload_triangles", C.c_int, vp)
+    sig("pt_upload_materials", C.c_int, vp)
+    sig("pt_seed_default", C.c_int, vp)
+    sig("pt_upload_seeds", C.c_int, vp, vp, i64)
+    sig("pt_generate_rays", C.c_int, vp, vp)
+    sig("pt_trace_rays", C.c_int, vp, vp, i32, i32)
+    sig("pt_render", C.c_int, vp, vp, i32, i32)
+    sig("pt_set_current_sample", C.c_int, vp, i32)
+    sig("pt_get_current_sample", C.c_int, vp, C.POINTER(i32))
+    sig("pt_sync", C.c_int, vp)
+    sig("pt_local_pixel_count", C.c_int, vp, C.POINTER(i64))
+    sig("pt_local_pixel_ids", C.c_int, vp, vp, i64)
+    sig("pt_read_colors", C.c_int, vp, vp, i64)
+    sig("pt_read_rnds", C.c_int, vp, vp, i64)
+    sig("pt_read_rays", C.c_int, vp, vp, i64)
+    sig("pt_resolve_ldr", C.c_int, vp, i32, vp, i64)
+    sig("pt_bind_framebuffer", C.c_int, vp, vp, vp)
+    sig("pt_device_colors", vp, vp)
+    sig("pt_device_rnds", vp, vp)
+    sig("pt_set_stream", C.c_int, vp, vp)
+    sig("pt_set_option", C.c_int, vp, C.c_char_p, i64)
+    sig("pt_get_stat", C.c_int, vp, C.c_char_p, C.POINTER(C.c_double))
+    sig("pt_debug_bvh_sizes", C.c_int, vp, C.POINTER(i64), C.POINTER(i64))
+    sig("pt_debug_bvh_copy", C.c_int, vp, vp, vp, vp, vp)
+    sig("pt_debug_encounter_rank", C.c_int, vp, vp, i64)
+    return L
+
+
+LIB = _load()
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def Material(kd, ks, emission, N, K, shininess, mtype):
+    """Material(kd,ks,emission,N,K,shininess,type), main.cpp:101-111 -> 80-byte record."""
+    m = np.zeros(1, dtype=MATERIAL)
+    LIB.pt_material_init(_ptr(m), _f3(kd), _f3(ks), _f3(emission), _f3(N), _f3(K), float(shininess), int(mtype))
+    return m
+
+
+def Triangle(r1, r2, r3, mati):
+    """Triangle(r1,r2,r3,mati), main.cpp:144-166 -> 80-byte record."""
+    t = np.zeros(1, dtype=TRIANGLE)
+    LIB.pt_triangle_init(_ptr(t), _f3(r1), _f3(r2), _f3(r3), int(mati))
+    return t
+
+
+def Camera(fov, yaw, pitch, shift, width, height):
+    """Camera(), main.cpp:311-347, with the globals it reads passed in."""
+    c = np.zeros(1, dtype=CAMERA)
+    LIB.pt_camera_init(_ptr(c), float(fov), float(yaw), float(pitch), _f3(shift), int(width), int(height))
+    return c
+
+
+def triangles_from_vertices(verts, mati):
+    """(n,3,3) float32 vertices + (n,) material indices -> (n,) TRIANGLE records."""
+    verts = np.ascontiguousarray(verts, dtype=np.float32)
+    out = np.zeros(verts.shape[0], dtype=TRIANGLE)
+    fp = C.POINTER(C.c_float)
+    for i in range(verts.shape[0]):
+        LIB.pt_triangle_init(out[i:i + 1].ctypes.data_as(C.c_void_p), verts[i, 0].ctypes.data_as(fp),
+                             verts[i, 1].ctypes.data_as(fp), verts[i, 2].ctypes.data_as(fp), int(mati[i]))
+    return out
+
+
+class Scene:
+    """The reference's Scene (main.cpp:363-742) on one MI355X.
+
+    device=None -> host-only context (authoring + BVH build only).  rank/world/rows_per_block
+    select this context's interleaved row blocks of the global frame (multi-GPU tiling)."""
+
+    def __init__(self, width, height, device=0, rank=0, world=1, rows_per_block=8):
+        self.width, self.height = int(width), int(height)
+        self.rank, self.world, self.rows_per_block = rank, world, rows_per_block
+        # the reference's mutable globals (main.cpp:27-39), shipped defaults replaced by the
+        # "canonical" view it keeps in comments (main.cpp:33-35, 40)
+        self.iterations = 1
+        self.fov, self.yaw, self.pitch, self.shift = 60.0, 0.0, 0.0, (0.0, 0.0, 0.0)
+        self._h = C.c_void_p()
+        dev = -1 if device is None else int(device)
+        rc = LIB.pt_create_tiled(dev, self.width, self.height, rank, world, rows_per_block, C.byref(self._h))
+        if rc != PT_OK:
+            raise PtError(rc, (LIB.pt_last_error(None) or b"").decode())
+        self.camera = Camera(self.fov, self.yaw, self.pitch, self.shift, self.width, self.height)
+
+    # -- plumbing
+    def _ck(self, rc):
+        if rc < 0:
+            raise PtError(rc, (LIB.pt_last_error(self._h) or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            LIB.pt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def list_info(self):                                   # Scene::list_info, main.cpp:389-455
+        buf = C.create_string_buffer(256)
+        self._ck(LIB.pt_device_info(self._h, buf, 256))
+        return buf.value.decode()
+
+    # -- authoring (main.cpp:529-617)
+    def add_Material(self, *args):
+        m = args[0] if len(args) == 1 else Material(*args)
+        return self._ck(LIB.pt_add_material(self._h, _ptr(m)))
+
+    def add_Triangle(self, *args):
+        t = args[0] if len(args) == 1 else Triangle(*args)
+        self._ck(LIB.pt_add_triangle(self._h, _ptr(t)))
+
+    def add_Triangles(self, tris):
+        tris = np.ascontiguousarray(tris, dtype=TRIANGLE)
+        self._ck(LIB.pt_add_triangles(self._h, _ptr(tris), tris.shape[0]))
+
+    def end_Obj(self):
+        self._ck(LIB.pt_end_obj(self._h))
+
+    def add_Obj(self, file, pos, scale, pitch, yaw):
+        self._ck(LIB.pt_add_obj(self._h, os.fsencode(file), _f3(pos), _f3(scale), float(pitch), float(yaw)))
+
+    def upload_Triangles(self):
+        self._ck(LIB.pt_upload_triangles(self._h))
+
+    def upload_Materials(self):
+        self._ck(LIB.pt_upload_materials(self._h))
+
+    def load(self, spec):
+        """Author a scenes.SceneSpec: materials, then one object per entry, then upload."""
+        for m in spec.materials:
+            self.add_Material(*m)
+        for verts, mati in spec.objects:
+            self.add_Triangles(triangles_from_vertices(verts, mati))
+            self.end_Obj()
+        self.upload_Triangles()
+        self.upload_Materials()
+        self.set_view(spec.fov, spec.yaw, spec.pitch, spec.shift)
+        return self
+
+    # -- camera / globals
+    def set_view(self, fov, yaw, pitch, shift):
+        self.fov, self.yaw, self.pitch, self.shift = fov, yaw, pitch, tuple(shift)
+        self.camera = Camera(fov, yaw, pitch, shift, self.width, self.height)
+
+    @property
+    def current_sample(self):
+        v = C.c_int32()
+        self._ck(LIB.pt_get_current_sample(self._h, C.byref(v)))
+        return v.value
+
+    @current_sample.setter
+    def current_sample(self, v):
+        self._ck(LIB.pt_set_current_sample(self._h, int(v)))
+
+    # -- the hot path (main.cpp:635-687)
+    def generate_rays(self):
+        self.camera = Camera(self.fov, self.yaw, self.pitch, self.shift, self.width, self.height)   # main.cpp:636
+        self._ck(LIB.pt_generate_rays(self._h, _ptr(self.camera)))
+
+    def trace_rays(self):
+        self._ck(LIB.pt_trace_rays(self._h, _ptr(self.camera), self.iterations, self.current_sample))
+
+    def render(self, nsamples=1, fused=True):
+        """nsamples x Scene::render().  fused=False issues the reference's two launches per
+        sample (generate_rays, trace_rays); fused=True is one persistent launch."""
+        if fused:
+            self._ck(LIB.pt_render(self._h, _ptr(self.camera), self.iterations, int(nsamples)))
+        else:
+            for _ in range(int(nsamples)):
+                self.generate_rays()
+                self.trace_rays()
+                self.current_sample = self.current_sample + 1                                        # main.cpp:686
+
+    def sync(self):
+        self._ck(LIB.pt_sync(self._h))
+
+    # -- seeds
+    def seed_default(self):
+        self._ck(LIB.pt_seed_default(self._h))
+
+    def upload_seeds(self, seeds):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        self._ck(LIB.pt_upload_seeds(self._h, _ptr(seeds), seeds.size))
+
+    # -- readback
+    @property
+    def local_pixels(self):
+        v = C.c_int64()
+        self._ck(LIB.pt_local_pixel_count(self._h, C.byref(v)))
+        return v.value
+
+    def local_pixel_ids(self):
+        out = np.empty(self.local_pixels, dtype=np.int32)
+        self._ck(LIB.pt_local_pixel_ids(self._h, _ptr(out), out.size))
+        return out
+
+    def read_colors(self):
+        out = np.empty((self.local_pixels, 4), dtype=np.float32)
+        self._ck(LIB.pt_read_colors(self._h, _ptr(out), out.shape[0]))
+        return out
+
+    def read_rnds(self):
+        out = np.empty(self.local_pixels, dtype=np.int32)
+        self._ck(LIB.pt_read_rnds(self._h, _ptr(out), out.size))
+        return out
+
+    def read_rays(self):
+        out = np.empty(self.local_pixels, dtype=RAY)
+        self._ck(LIB.pt_read_rays(self._h, _ptr(out), out.size))
+        return out
+
+    def resolve_ldr(self, which=0):
+        out = np.empty((self.local_pixels, 4), dtype=np.float32)
+        self._ck(LIB.pt_resolve_ldr(self._h, int(which), _ptr(out), out.shape[0]))
+        return out
+
+    # -- options / stats / device plumbing
+    def set_option(self, key, value):
+        self._ck(LIB.pt_set_option(self._h, key.encode(), int(value)))
+
+    def stat(self, key):
+        v = C.c_double()
+        self._ck(LIB.pt_get_stat(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def bind_framebuffer(self, colors_ptr, rnds_ptr):
+        self._ck(LIB.pt_bind_framebuffer(self._h, C.c_void_p(colors_ptr), C.c_void_p(rnds_ptr)))
+
+    def set_stream(self, stream_ptr):
+        self._ck(LIB.pt_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def device_colors(self):
+        return LIB.pt_device_colors(self._h)
+
+    def device_rnds(self):
+        return LIB.pt_device_rnds(self._h)
+
+    # -- introspection (host data)
+    def debug_bvh(self):
+        nn, nt = C.c_int64(), C.c_int64()
+        self._ck(LIB.pt_debug_bvh_sizes(self._h, C.byref(nn), C.byref(nt)))
+        nodes = np.zeros((nn.value, 16), dtype=np.float32)
+        tris = np.zeros((nt.value, 12), dtype=np.float32)
+        meta = np.zeros((nt.value, 2), dtype=np.int32)
+        orig = np.zeros(nt.value, dtype=np.int32)
+        self._ck(LIB.pt_debug_bvh_copy(self._h, _ptr(nodes), _ptr(tris), _ptr(meta), _ptr(orig)))
+        return nodes, tris, meta, orig
+
+    def debug_encounter_rank(self, n):
+        out = np.empty(n, dtype=np.int32)
+        self._ck(LIB.pt_debug_encounter_rank(self._h, _ptr(out), n))
+        return out

@@ -1,0 +1,79 @@
+// pt_internal.hpp -- shared between the host side (pt_host.cpp) and the device side
+// (pt_kernels.hip) of libptamd.so.  Not part of the public ABI (that is include/pt_api.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pt_api.h"
+
+namespace ptamd {
+
+// ---- packed scene layout in HBM ----------------------------------
+// BVH2 node, 64 B = 4 x float4.  A node stores the boxes of BOTH children so one fetch
+// decides both descents:
+//   q[a] (a = 0,1,2 = x,y,z) = { Lmin[a], Lmax[a], Rmin[a], Rmax[a] }
+//   q[3] = { bits(left), bits(right), 0, 0 }
+// child reference >= 0: interior node index; < 0: leaf, ~ref = (first << 3) | (count - 1).
+struct Node64 {
+    float q[3][4];
+    int32_t left, right;
+    int32_t pad[2];
+};
+static_assert(sizeof(Node64) == 64, "Node64 must be 64 B");
+
+// Triangle packet, 48 B = 3 x float4: { r1.xyz r2.x | r2.yz r3.xy | r3.z N.xyz } -- exactly the
+// twelve floats prog.cl:94-112 reads, nothing derived (the hit test is bit-defined by them).
+struct TriPacket {
+    float v[12];
+};
+static_assert(sizeof(TriPacket) == 48, "TriPacket must be 48 B");
+
+// per packed triangle: encounter rank in the reference's traversal (tie-break), material index
+struct TriMeta {
+    int32_t rank;
+    int32_t mati;
+};
+
+constexpr int kMaxLeaf = 4;        // triangles per leaf (<= 8 by the reference encoding)
+constexpr int kMaxDepth = 30;      // builder guarantees depth <= kMaxDepth
+constexpr int kStackEntries = 32;  // upper bound of the per-lane traversal stack (far children only)
+
+// ---- kernel parameter block (passed by value, like `Camera` in prog.cl:292-304) ----------
+struct RenderParams {
+    const float4* nodes;
+    const float4* tris;
+    const TriMeta* meta;
+    const pt_material* mats;
+    int32_t* rnds;          // local pixels
+    float4* colors;         // local pixels, float3 @ 16 B
+    pt_ray* rays;           // local pixels
+    unsigned long long* stats;   // [0] segments, [1] samples
+    pt_camera cam;
+    int32_t width, height;       // GLOBAL frame
+    int32_t local_rows;          // rows owned by this context
+    int32_t rank, world, rows_per_block;
+    int32_t iterations, first_sample, nsamples;
+    int32_t n_nodes, n_tris;
+    int32_t lds_scene;           // 1: stage nodes+triangles in LDS
+    int32_t stack_entries;       // per-lane stack depth actually needed (BVH depth + 1)
+};
+
+struct LaunchConfig {
+    int block = 256;
+    size_t lds_bytes = 0;
+};
+
+// launchers implemented in pt_kernels.hip; all asynchronous on `stream`
+hipError_t launch_gen_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream);
+hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream);
+hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream);
+hipError_t launch_resolve_reinhard(const float4* colors, float4* out, int64_t n, hipStream_t stream);
+hipError_t launch_filt_im(const float4* colors, float4* out, int32_t width, int32_t height, hipStream_t stream);
+size_t mega_lds_bytes(const RenderParams& p, int block);
+int mega_max_lds_scene_bytes();
+
+}  // namespace ptamd

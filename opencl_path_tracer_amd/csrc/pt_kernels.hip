@@ -1,0 +1,653 @@
+// pt_kernels.hip -- gfx950 device code of libptamd.so.
+//
+// The hot path of the reference (prog.cl:292-389: gen_ray + trace_ray) as one persistent
+// "render" kernel: every lane owns one pixel and runs ALL requested samples of it back to
+// back with the whole path state in registers (the per-pixel LCG stream is sequential across
+// samples, prog.cl:72-77 + main.cpp:382, so a pixel's samples can never run concurrently
+// anyway).  A lane whose path ends regenerates its next camera ray in the same loop, so the
+// wave stays converged on "traverse -> shade" instead of idling until the longest path of
+// the wave is done.  HBM traffic per sample is ~0: rnds/colors are read once and written
+// once per launch.
+//
+// Traversal: own BVH2 (64-B nodes holding both child boxes, 48-B triangle packets), near
+// child first, far child pushed on a per-lane stack that lives in LDS ([entry][lane], bank =
+// lane: conflict-free).  When nodes + packets fit, the workgroup first stages the WHOLE scene
+// in LDS (Cornell box: 1,932 triangles = 132 KiB) and never touches HBM again for geometry.
+//
+// Arithmetic: compiled with -ffp-contract=off; the only fused operations are the explicit
+// fma calls, placed as DESIGN.md section 3 prescribes, so that results can be compared bit
+// for bit with the CPU oracle.  '/' and sqrt are IEEE (hipcc default for HIP), sin/cos/pow are
+// the double-precision polynomial routines below.  Box tests are NOT part of that contract:
+// they are conservative (padded boxes, widened slabs) and only ever cull.
+#include "pt_internal.hpp"
+
+namespace ptamd {
+
+// ---------------------------------------------------------------------------- small math
+struct f3 {
+    float x, y, z;
+};
+#define PT_DEV __device__ __forceinline__
+
+PT_DEV f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV f3 ldf3(const pt_float3& p) { return mk(p.s[0], p.s[1], p.s[2]); }
+PT_DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+PT_DEV f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+PT_DEV float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PT_DEV double fmad_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// u*s + w, one fma per component
+PT_DEV f3 madd(f3 u, float s, f3 w) { return mk(fmaf_(u.x, s, w.x), fmaf_(u.y, s, w.y), fmaf_(u.z, s, w.z)); }
+PT_DEV float dot3(f3 a, f3 b) { return fmaf_(a.z, b.z, fmaf_(a.y, b.y, a.x * b.x)); }
+PT_DEV f3 cross3(f3 a, f3 b) {
+    return mk(fmaf_(a.y, b.z, -(a.z * b.y)), fmaf_(a.z, b.x, -(a.x * b.z)), fmaf_(a.x, b.y, -(a.y * b.x)));
+}
+PT_DEV f3 normalize3(f3 a) {
+    const float s = 1.0f / __builtin_sqrtf(dot3(a, a));
+    return a * s;
+}
+PT_DEV float max0(float c) { return c > 0.0f ? c : 0.0f; }
+
+// ---- spec math: double polynomials, rounded once to float
+PT_DEV void spec_sincos(float theta, float* s, float* c) {
+    const double t = (double)theta;
+    const int q = (int)fmad_(t, 0.63661977236758138, 0.5);
+    const double qd = (double)q;
+    double r = fmad_(qd, -1.5707963267948966, t);
+    r = fmad_(qd, -6.123233995736766e-17, r);
+    const double z = r * r;
+    double ps = 1.6059043836821613e-10;
+    ps = fmad_(ps, z, -2.505210838544172e-08);
+    ps = fmad_(ps, z, 2.7557319223985893e-06);
+    ps = fmad_(ps, z, -0.0001984126984126984);
+    ps = fmad_(ps, z, 0.008333333333333333);
+    ps = fmad_(ps, z, -0.16666666666666666);
+    const double sr = fmad_(r * z, ps, r);
+    double pc = -1.1470745597729725e-11;
+    pc = fmad_(pc, z, 2.08767569878681e-09);
+    pc = fmad_(pc, z, -2.755731922398589e-07);
+    pc = fmad_(pc, z, 2.48015873015873e-05);
+    pc = fmad_(pc, z, -0.001388888888888889);
+    pc = fmad_(pc, z, 0.041666666666666664);
+    pc = fmad_(pc, z, -0.5);
+    const double cr = fmad_(z, pc, 1.0);
+    const int k = q & 3;
+    const double sv = (k == 0) ? sr : (k == 1) ? cr : (k == 2) ? -sr : -cr;
+    const double cv = (k == 0) ? cr : (k == 1) ? -sr : (k == 2) ? -cr : sr;
+    *s = (float)sv;
+    *c = (float)cv;
+}
+
+PT_DEV float spec_pow5(float x) {
+    const float x2 = x * x;
+    const float x4 = x2 * x2;
+    return x4 * x;
+}
+
+PT_DEV float spec_pow(float x, float y) {
+    if (y == 0.0f) return 1.0f;
+    if (x != x || y != y) return __builtin_nanf("");
+    if (x < 0.0f) return __builtin_nanf("");
+    if (x == 0.0f) return y > 0.0f ? 0.0f : __builtin_inff();
+    if (__builtin_isinf(x)) return y > 0.0f ? __builtin_inff() : 0.0f;
+    const double xd = (double)x;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(xd);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m = __longlong_as_double((long long)bits);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double sdiv = f / (2.0 + f);
+    const double z = sdiv * sdiv;
+    double p = 0.10526315789473684;
+    p = fmad_(p, z, 0.11764705882352941);
+    p = fmad_(p, z, 0.13333333333333333);
+    p = fmad_(p, z, 0.15384615384615385);
+    p = fmad_(p, z, 0.18181818181818182);
+    p = fmad_(p, z, 0.22222222222222221);
+    p = fmad_(p, z, 0.2857142857142857);
+    p = fmad_(p, z, 0.4);
+    p = fmad_(p, z, 0.66666666666666663);
+    p = fmad_(p, z, 2.0);
+    const double lnm = sdiv * p;
+    const double lg2 = fmad_(lnm, 1.4426950408889634, (double)e);
+    const double w = (double)y * lg2;
+    if (!(w > -126.0)) return 0.0f;
+    if (w >= 128.0) return __builtin_inff();
+    const double nd = __builtin_floor(w + 0.5);
+    const double g = (w - nd) * 0.6931471805599453;
+    double q = 2.08767569878681e-09;
+    q = fmad_(q, g, 2.505210838544172e-08);
+    q = fmad_(q, g, 2.755731922398589e-07);
+    q = fmad_(q, g, 2.7557319223985893e-06);
+    q = fmad_(q, g, 2.48015873015873e-05);
+    q = fmad_(q, g, 0.0001984126984126984);
+    q = fmad_(q, g, 0.001388888888888889);
+    q = fmad_(q, g, 0.008333333333333333);
+    q = fmad_(q, g, 0.041666666666666664);
+    q = fmad_(q, g, 0.16666666666666666);
+    q = fmad_(q, g, 0.5);
+    q = fmad_(q, g, 1.0);
+    q = fmad_(q, g, 1.0);
+    const unsigned long long sb = (unsigned long long)((long long)nd + 1023) << 52;
+    const double sc = __longlong_as_double((long long)sb);
+    return (float)(q * sc);
+}
+
+// ---- LCG, prog.cl:72-77
+PT_DEV float lcg_rand(int& seed) {
+    unsigned long long n = (unsigned long long)(long long)seed;
+    n = (n * 48271ull) % 2147483647ull;
+    seed = (int)n;
+    return (float)n / 2147483648.0f;
+}
+
+// ---------------------------------------------------------------------------- pixel map
+// One wave covers an 8x8 pixel tile of the LOCAL frame (width x local_rows).
+struct PixelId {
+    int li;   // local pixel index (buffer index), -1 = none
+    int gid;  // global pixel id (what prog.cl calls id)
+};
+PT_DEV PixelId pixel_of_thread(const RenderParams& p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int tiles_x = (p.width + 7) >> 3;
+    const int ty = wave / tiles_x, tx = wave - ty * tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int lrow = ty * 8 + (lane >> 3);
+    PixelId r;
+    if (x >= p.width || lrow >= p.local_rows) {
+        r.li = -1;
+        r.gid = 0;
+        return r;
+    }
+    const int grow = ((lrow / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (lrow % p.rows_per_block);
+    r.li = lrow * p.width + x;
+    r.gid = grow * p.width + x;
+    return r;
+}
+
+// ---------------------------------------------------------------------------- camera, prog.cl:82-92
+PT_DEV void camera_get_ray(int id, const pt_camera& cam, float rnd1, float rnd2, f3* P, f3* D) {
+    const int X = (int)cam.XM;
+    const int Y = (int)cam.YM;
+    const float x = (float)(id % X) + rnd1;
+    const float y = (float)(id / X) + rnd2;
+    const f3 right = ldf3(cam.right) * ((2.0f * x) / (float)X - 1.0f);
+    const f3 up = ldf3(cam.up) * ((2.0f * y) / (float)Y - 1.0f);
+    const f3 pp = (ldf3(cam.lookat) + right) + up;
+    const f3 eye = ldf3(cam.eye);
+    *P = eye;
+    *D = normalize3(pp - eye);
+}
+
+// ---------------------------------------------------------------------------- traversal
+struct SceneView {
+    const float4* nodes;   // global or LDS
+    const float4* tris;    // global or LDS
+    const TriMeta* meta;   // global
+};
+
+// prog.cl:94-112 on one packet; returns t (> 0) or -1
+PT_DEV float tri_test(const float4 a, const float4 b, const float4 c, f3 P, f3 Vd) {
+    const f3 r1 = mk(a.x, a.y, a.z), r2 = mk(a.w, b.x, b.y), r3 = mk(b.z, b.w, c.x), N = mk(c.y, c.z, c.w);
+    const float t = dot3(r1 - P, N) / dot3(Vd, N);
+    const f3 pt = madd(Vd, t, P);
+    const float c1 = dot3(cross3(r2 - r1, pt - r1), N);
+    const float c2 = dot3(cross3(r3 - r2, pt - r2), N);
+    const float c3 = dot3(cross3(r1 - r3, pt - r3), N);
+    const bool ok = !(t < 0.0f) && (c1 >= 0.0f) && (c2 >= 0.0f) && (c3 >= 0.0f) && (t > 0.0f);
+    return ok ? t : -1.0f;
+}
+
+// closest hit over the whole scene; ties in t go to the lower encounter rank (the triangle
+// the reference's traversal, prog.cl:113-184, meets first).  Returns packed triangle index or -1.
+template <bool LDS_SCENE>
+PT_DEV int closest_hit(const SceneView& sv, f3 P, f3 D, unsigned* stk, const int stride, float* t_out) {
+    const float kWiden = 1.0000005f;   // > 4 ulp: covers rcp + sub + mul rounding of the slab test
+    const f3 inv = mk(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
+    float best_t = __builtin_inff();
+    int best = -1;
+    int sp = 0;
+    int cur = 0;  // root is always an interior node
+    for (;;) {
+        // ---- interior node: test both children
+        const float4 qx = sv.nodes[cur * 4 + 0];
+        const float4 qy = sv.nodes[cur * 4 + 1];
+        const float4 qz = sv.nodes[cur * 4 + 2];
+        const float4 qr = sv.nodes[cur * 4 + 3];
+        const float lx0 = (qx.x - P.x) * inv.x, lx1 = (qx.y - P.x) * inv.x;
+        const float rx0 = (qx.z - P.x) * inv.x, rx1 = (qx.w - P.x) * inv.x;
+        const float ly0 = (qy.x - P.y) * inv.y, ly1 = (qy.y - P.y) * inv.y;
+        const float ry0 = (qy.z - P.y) * inv.y, ry1 = (qy.w - P.y) * inv.y;
+        const float lz0 = (qz.x - P.z) * inv.z, lz1 = (qz.y - P.z) * inv.z;
+        const float rz0 = (qz.z - P.z) * inv.z, rz1 = (qz.w - P.z) * inv.z;
+        const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
+        const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1)) * kWiden;
+        const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
+        const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1)) * kWiden;
+        const float lim = best_t * kWiden;
+        const bool hl = (lf >= ln) && (lf >= 0.0f) && (ln <= lim);
+        const bool hr = (rf >= rn) && (rf >= 0.0f) && (rn <= lim);
+        const int li = __float_as_int(qr.x), ri = __float_as_int(qr.y);
+        int next;
+        if (hl && hr) {
+            const bool lfirst = ln <= rn;
+            next = lfirst ? li : ri;
+            stk[sp * stride] = (unsigned)(lfirst ? ri : li);
+            ++sp;
+        } else if (hl) {
+            next = li;
+        } else if (hr) {
+            next = ri;
+        } else {
+            if (sp == 0) break;
+            --sp;
+            next = (int)stk[sp * stride];
+        }
+        // ---- leaves: intersect, then pop, until an interior node is current again
+        bool done = false;
+        while (next < 0) {
+            const int v = ~next;
+            const int first = v >> 3, count = (v & 7) + 1;
+            for (int k = 0; k < count; ++k) {
+                const int ti = first + k;
+                const float4 a = sv.tris[ti * 3 + 0], b = sv.tris[ti * 3 + 1], c = sv.tris[ti * 3 + 2];
+                const float t = tri_test(a, b, c, P, D);
+                if (t > 0.0f) {
+                    bool better = t < best_t;
+                    if (t == best_t && best >= 0) better = sv.meta[ti].rank < sv.meta[best].rank;
+                    if (better) { best_t = t; best = ti; }
+                }
+            }
+            if (sp == 0) { done = true; break; }
+            --sp;
+            next = (int)stk[sp * stride];
+        }
+        if (done) break;
+        cur = next;
+    }
+    *t_out = best_t;
+    return best;
+}
+
+// ---------------------------------------------------------------------------- BSDF sampling
+struct RayPD {
+    f3 P, D;
+};
+
+// prog.cl:186-218
+PT_DEV RayPD new_ray_diffuse(f3 hp, f3 N, float rnd1, float rnd2) {
+    const float E = 0.001f;
+    const bool yaxis = __builtin_fabsf(N.x) <= E && __builtin_fabsf(N.z) <= E;
+    const float other = yaxis ? N.y : N.x;
+    const float rl = 1.0f / __builtin_sqrtf(fmaf_(N.z, N.z, other * other));
+    const f3 Z = yaxis ? mk(0.0f, -N.z * rl, N.y * rl) : mk(-N.z * rl, 0.0f, N.x * rl);
+    const f3 X = cross3(N, Z);
+    const float r = __builtin_sqrtf(rnd1);
+    const float theta = (float)(6.283185307179586 * (double)rnd2);
+    float sn, cs;
+    spec_sincos(theta, &sn, &cs);
+    const float x = r * cs, y = r * sn, z = __builtin_sqrtf(1.0f - rnd1);
+    f3 d = X * x;
+    d = madd(N, z, d);
+    d = madd(Z, y, d);
+    RayPD o;
+    o.P = madd(N, E, hp);
+    o.D = normalize3(d);
+    return o;
+}
+
+// prog.cl:219-222
+PT_DEV f3 fresnel(f3 F0, f3 N, f3 D) {
+    const float cosa = __builtin_fabsf(dot3(N, D));
+    const float p5 = spec_pow5(1.0f - cosa);
+    return mk(fmaf_(1.0f - F0.x, p5, F0.x), fmaf_(1.0f - F0.y, p5, F0.y), fmaf_(1.0f - F0.z, p5, F0.z));
+}
+
+// prog.cl:223-227
+PT_DEV RayPD new_ray_specular(f3 hp, f3 N, f3 oldD) {
+    const float cosa = dot3(N, oldD);
+    RayPD o;
+    o.D = normalize3(oldD - (N * cosa) * 2.0f);
+    o.P = madd(N, 0.001f, hp);
+    return o;
+}
+
+// prog.cl:228-245; *flipped = the path crossed the interface (in = !in)
+PT_DEV RayPD new_ray_refractive(f3 hp, f3 N, f3 F0, float n, f3 oldD, bool in, float rnd, bool* flipped) {
+    if (in) n = 1.0f / n;
+    const float cosa = dot3(-oldD, N);
+    const float disc = 1.0f - (fmaf_(-cosa, cosa, 1.0f) / n) / n;
+    const f3 F = fresnel(F0, N, oldD);
+    const float prob = ((F.x + F.y) + F.z) / 3.0f;
+    const bool refr = disc > 0.0f && rnd > prob;
+    *flipped = refr;
+    // both candidate directions before normalisation; one normalize serves either branch
+    const f3 dn = mk(oldD.x / n, oldD.y / n, oldD.z / n);
+    const f3 dr = madd(N, cosa / n - __builtin_sqrtf(disc), dn);
+    const f3 dm = oldD - (N * dot3(N, oldD)) * 2.0f;
+    RayPD o;
+    o.D = normalize3(refr ? dr : dm);
+    o.P = madd(N, refr ? -0.001f : 0.001f, hp);
+    return o;
+}
+
+// ---------------------------------------------------------------------------- path state + shading
+// The path state of prog.cl:307-316 lives in plain local variables (registers), passed by
+// reference: P, D, the four factors, the colour, the LCG state and the inside-glass flag.
+#define PT_PATH_ARGS f3 &rP, f3 &rD, f3 &fL, f3 &fB, f3 &fS, f3 &fR, f3 &color, int &seed, bool &inside
+
+// one iteration body of prog.cl:317-366 for a ray that hit packed triangle `ti` at `t`
+PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, const TriMeta* meta, int ti, float t) {
+    const float4 c = tris[ti * 3 + 2];
+    f3 N = mk(c.y, c.z, c.w);
+    const f3 hp = madd(rD, t, rP);
+    const pt_material* __restrict__ m = &p.mats[meta[ti].mati];
+    const int type = m->type;
+    if (p.iterations == 1) color = ldf3(m->kd) + ldf3(m->emission);         // prog.cl:323-325
+    if (dot3(rD, N) > 0.0f) N = -N;                                         // prog.cl:326-328
+    if (type == 0) {                                                        // prog.cl:329-340
+        const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+        const RayPD nr = new_ray_diffuse(hp, N, rnd1, rnd2);
+        const f3 nP = nr.P, nD = nr.D;
+        const float idiff = max0(dot3(nD, N));
+        fL = fL * (ldf3(m->kd) * idiff);
+        const f3 view = normalize3(ldf3(p.cam.eye) - hp);
+        const f3 halfway = normalize3(view + nD);
+        const float ispec = max0(dot3(N, halfway));
+        fB = fB * (ldf3(m->ks) * spec_pow(ispec, m->shininess));
+        rP = nP;
+        rD = nD;
+    } else if (type == 1) {                                                 // prog.cl:341-345
+        const f3 oldD = rD;
+        const RayPD nr = new_ray_specular(hp, N, oldD);
+        fS = fS * fresnel(ldf3(m->F0), N, oldD);
+        rP = nr.P;
+        rD = nr.D;
+    } else if (type == 2) {                                                 // prog.cl:346-357
+        const f3 oldD = rD;
+        const float rnd = lcg_rand(seed);
+        const f3 F0 = ldf3(m->F0);
+        bool flipped;
+        const RayPD nr = new_ray_refractive(hp, N, F0, m->n, oldD, inside, rnd, &flipped);
+        const f3 F = fresnel(F0, N, oldD);
+        const float prob = ((F.x + F.y) + F.z) / 3.0f;
+        if (flipped) {
+            const float k = 1.0f / (1.0f - prob);
+            fR = (fR * mk(1.0f - F.x, 1.0f - F.y, 1.0f - F.z)) * k;
+        } else {
+            const float k = 1.0f / prob;
+            fR = (fR * F) * k;
+        }
+        inside = inside != flipped;
+        rP = nr.P;
+        rD = nr.D;
+    } else if (type == 3) {                                                 // prog.cl:358-366
+        const float inten = max0(dot3(-rD, N));
+        const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+        const RayPD nr = new_ray_diffuse(hp, N, rnd1, rnd2);
+        const f3 e = ((ldf3(m->emission) * (fL + fB)) * fS) * fR;
+        color = madd(e, inten, color);
+        rP = nr.P;
+        rD = nr.D;
+    }
+    // any other type: the ray is left unchanged and the loop hits the same surface again
+}
+
+PT_DEV f3 running_mean(f3 acc, f3 color, int s) {   // prog.cl:379
+    const float cs = (float)s, cs1 = (float)(s + 1);
+    return mk(fmaf_(acc.x, cs, color.x) / cs1, fmaf_(acc.y, cs, color.y) / cs1, fmaf_(acc.z, cs, color.z) / cs1);
+}
+
+// ---------------------------------------------------------------------------- LDS staging
+extern __shared__ __attribute__((aligned(16))) unsigned char pt_lds_raw[];
+
+PT_DEV void stage_scene(const RenderParams& p, float4* lds_nodes, float4* lds_tris) {
+    const int nn = p.n_nodes * 4, nt = p.n_tris * 3;
+    for (int i = threadIdx.x; i < nn; i += blockDim.x) lds_nodes[i] = p.nodes[i];
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) lds_tris[i] = p.tris[i];
+    __syncthreads();
+}
+
+PT_DEV unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------- kernels
+// gen_ray, prog.cl:384-389
+__global__ void __launch_bounds__(256) k_gen_ray(RenderParams p) {
+    const PixelId px = pixel_of_thread(p);
+    if (px.li < 0) return;
+    int seed = p.rnds[px.li];
+    const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+    f3 P, D;
+    camera_get_ray(px.gid, p.cam, rnd1, rnd2, &P, &D);
+    p.rnds[px.li] = seed;
+    float4* r = reinterpret_cast<float4*>(&p.rays[px.li]);
+    r[0] = make_float4(P.x, P.y, P.z, 0.0f);
+    r[1] = make_float4(D.x, D.y, D.z, 0.0f);
+}
+
+// The render kernel.  SPLIT = true: trace_ray alone (prog.cl:292-381), the ray comes from the
+// rays buffer and one sample is taken; SPLIT = false: nsamples x (gen_ray + trace_ray).
+template <bool SPLIT, bool LDS_SCENE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_render(RenderParams p) {
+    unsigned* stk = reinterpret_cast<unsigned*>(pt_lds_raw) + threadIdx.x;   // [entry][lane]
+    SceneView sv;
+    sv.nodes = p.nodes;
+    sv.tris = p.tris;
+    sv.meta = p.meta;
+    if (LDS_SCENE) {
+        float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + (size_t)p.stack_entries * 4 * BLOCK);
+        float4* lds_tris = lds_nodes + p.n_nodes * 4;
+        stage_scene(p, lds_nodes, lds_tris);
+        sv.nodes = lds_nodes;
+        sv.tris = lds_tris;
+    }
+    const PixelId px = pixel_of_thread(p);
+    unsigned long long segs = 0, samples = 0;
+    if (px.li >= 0) {
+        f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
+        f3 fL = mk(1.f, 1.f, 1.f), fB = fL, fS = fL, fR = fL, color = mk(0.f, 0.f, 0.f);
+        bool inside = false;
+        int seed = p.rnds[px.li];
+        f3 acc = mk(0.0f, 0.0f, 0.0f);
+        if (p.first_sample != 0) {             // prog.cl:312-314: sample 0 starts from black
+            const float4 c = p.colors[px.li];
+            acc = mk(c.x, c.y, c.z);
+        }
+        int s = p.first_sample;
+        const int s_end = p.first_sample + p.nsamples;
+        int bounce = 0;
+        bool fresh = true;
+        for (;;) {
+            if (fresh) {
+                if (s == s_end) break;
+                fL = mk(1.f, 1.f, 1.f);        // prog.cl:307-316
+                fB = fL;
+                fS = fL;
+                fR = fL;
+                color = mk(0.f, 0.f, 0.f);
+                inside = false;
+                if (SPLIT) {
+                    const float4* r = reinterpret_cast<const float4*>(&p.rays[px.li]);
+                    const float4 a = r[0], b = r[1];
+                    rP = mk(a.x, a.y, a.z);
+                    rD = mk(b.x, b.y, b.z);
+                } else {
+                    const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+                    camera_get_ray(px.gid, p.cam, rnd1, rnd2, &rP, &rD);
+                }
+                bounce = 0;
+                fresh = false;
+            }
+            bool finished = true;
+            if (bounce < p.iterations) {
+                float t;
+                const int ti = closest_hit<LDS_SCENE>(sv, rP, rD, stk, BLOCK, &t);
+                ++segs;
+                if (ti >= 0) {
+                    shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, ti, t);
+                    ++bounce;
+                    finished = (bounce >= p.iterations);
+                }
+            }
+            if (finished) {
+                acc = running_mean(acc, color, s);
+                ++s;
+                ++samples;
+                fresh = true;
+            }
+        }
+        p.colors[px.li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        p.rnds[px.li] = seed;
+        if (SPLIT) {
+            float4* r = reinterpret_cast<float4*>(&p.rays[px.li]);
+            r[0] = make_float4(rP.x, rP.y, rP.z, 0.0f);
+            r[1] = make_float4(rD.x, rD.y, rD.z, 0.0f);
+        }
+    }
+    segs = wave_sum(segs);
+    samples = wave_sum(samples);
+    if ((threadIdx.x & 63) == 0 && p.stats) {
+        atomicAdd(&p.stats[0], segs);
+        atomicAdd(&p.stats[1], samples);
+    }
+}
+
+// ---- tone mapping, prog.cl:247-269 (value of write_imagef at prog.cl:380)
+PT_DEV float srgb1(float a) {
+    if (a <= 0.00304f) return 12.92f * a;
+    return fmaf_(1.055f, spec_pow(a, 0.4167f), -0.055f);
+}
+__global__ void __launch_bounds__(256) k_resolve_reinhard(const float4* colors, float4* out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = colors[i];
+    const float L = fmaf_(0.0722f, c.z, fmaf_(0.7152f, c.y, 0.2126f * c.x));
+    const float L2 = L / (1.0f + L);
+    out[i] = make_float4(srgb1(c.x * L2 / L), srgb1(c.y * L2 / L), srgb1(c.z * L2 / L), 1.0f);
+}
+
+// filt_im, prog.cl:391-427: 3x3 median by mean grey + filmic tone map; the reference's
+// out-of-range reads at the right/top border (prog.cl:397-401) are not reproduced: border
+// pixels are left untouched.
+PT_DEV float filmic1(float cin) {   // prog.cl:259-263
+    float c = cin - 0.004f;
+    c = c > 0.0f ? c : 0.0f;
+    return (c * fmaf_(c, 6.2f, 0.5f)) / fmaf_(c, fmaf_(c, 6.2f, 1.7f), 0.06f);
+}
+__global__ void __launch_bounds__(256) k_filt_im(const float4* colors, float4* out, int W, int H) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x <= 0 || y <= 0 || x >= W - 1 || y >= H - 1) return;
+    float4 arr[9];
+    float grey[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float4 c = colors[(size_t)(y - 1 + i) * W + (x - 1 + j)];
+            arr[i * 3 + j] = c;
+            grey[i * 3 + j] = ((c.x + c.y) + c.z) / 3.0f;
+        }
+#pragma unroll
+    for (int jn = 9; jn > 1; --jn) {
+        int maxi = 0;
+#pragma unroll
+        for (int i = 1; i < jn; ++i)
+            if (grey[i] > grey[maxi]) maxi = i;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {       // swap without dynamic register indexing
+            if (i == maxi) {
+                const float tg = grey[jn - 1];
+                const float4 tv = arr[jn - 1];
+                grey[jn - 1] = grey[i];
+                arr[jn - 1] = arr[i];
+                grey[i] = tg;
+                arr[i] = tv;
+            }
+        }
+    }
+    out[(size_t)y * W + x] = make_float4(filmic1(arr[4].x), filmic1(arr[4].y), filmic1(arr[4].z), 1.0f);
+}
+
+// ---------------------------------------------------------------------------- launchers
+static inline int n_waves(const RenderParams& p) {
+    const int tiles_x = (p.width + 7) >> 3, tiles_y = (p.local_rows + 7) >> 3;
+    return tiles_x * tiles_y;
+}
+
+int mega_max_lds_scene_bytes() { return 160 * 1024; }
+
+size_t mega_lds_bytes(const RenderParams& p, int block) {
+    size_t b = (size_t)p.stack_entries * 4 * (size_t)block;
+    if (p.lds_scene) b += (size_t)p.n_nodes * 64 + (size_t)p.n_tris * 48;
+    return b;
+}
+
+hipError_t launch_gen_ray(const RenderParams& p, const LaunchConfig&, hipStream_t stream) {
+    const int waves = n_waves(p);
+    if (waves == 0) return hipSuccess;
+    const int blocks = (waves + 3) / 4;
+    hipLaunchKernelGGL(k_gen_ray, dim3(blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <bool SPLIT>
+static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
+    const int waves = n_waves(p);
+    if (waves == 0) return hipSuccess;
+    const int wpb = lc.block / 64;
+    const int blocks = (waves + wpb - 1) / wpb;
+    const size_t lds = lc.lds_bytes;
+#define PT_LAUNCH(LDS, B)                                                                          \
+    do {                                                                                           \
+        auto kern = k_render<SPLIT, LDS, B>;                                                       \
+        if (lds > 64 * 1024) {                                                                     \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                         \
+        }                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(B), lds, stream, p);                           \
+        return hipGetLastError();                                                                  \
+    } while (0)
+    if (p.lds_scene) {
+        switch (lc.block) {
+        case 64: PT_LAUNCH(true, 64);
+        case 128: PT_LAUNCH(true, 128);
+        case 256: PT_LAUNCH(true, 256);
+        case 512: PT_LAUNCH(true, 512);
+        case 1024: PT_LAUNCH(true, 1024);
+        }
+    } else {
+        switch (lc.block) {
+        case 64: PT_LAUNCH(false, 64);
+        case 128: PT_LAUNCH(false, 128);
+        case 256: PT_LAUNCH(false, 256);
+        case 512: PT_LAUNCH(false, 512);
+        case 1024: PT_LAUNCH(false, 1024);
+        }
+    }
+#undef PT_LAUNCH
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) { return launch_render_t<true>(p, lc, stream); }
+hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) { return launch_render_t<false>(p, lc, stream); }
+
+hipError_t launch_resolve_reinhard(const float4* colors, float4* out, int64_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve_reinhard, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, colors, out, (long long)n);
+    return hipGetLastError();
+}
+
+hipError_t launch_filt_im(const float4* colors, float4* out, int32_t W, int32_t H, hipStream_t stream) {
+    hipLaunchKernelGGL(k_filt_im, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, stream, colors, out, W, H);
+    return hipGetLastError();
+}
+
+}  // namespace ptamd

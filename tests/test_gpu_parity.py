@@ -1,0 +1,243 @@
+"""-m gpu: the HIP path (through the C ABI, libptamd.so) against the CPU oracle on the same
+scene and seeds.
+
+Bar (BASELINE.json north_star): relative L2 over all colors RGB values <= 1e-3 at equal spp.
+Because the oracle and the kernels follow the same bit-defined arithmetic contract
+ the tests demand more: identical colors bits and identical final LCG state
+in every pixel ("diverged pixels == 0").  rel-L2 is still computed and asserted."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_REL_L2 = 1e-3
+
+
+def rel_l2(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32), np.ascontiguousarray(b, np.float32).view(np.uint32))
+
+
+def oracle_render(oracle, osc, spec, W, H, bounces, spp, mode=0):
+    cam = oracle.make_camera(spec.fov, spec.yaw, spec.pitch, spec.shift, W, H)
+    fr = oracle.OracleFrame(W, H)
+    segs = fr.render(osc, cam, bounces, 0, spp, mode=mode, nthreads=16)
+    return fr, segs
+
+
+def check(sc, fr, what=""):
+    cols, rnds = sc.read_colors(), sc.read_rnds()
+    ocols, ornds = fr.colors(), fr.rnds()
+    diverged = int((rnds != ornds).sum())
+    err = rel_l2(cols[:, :3], ocols[:, :3])
+    assert err <= TOL_REL_L2, "%s rel-L2 %g" % (what, err)
+    assert diverged == 0, "%s: %d pixels consumed a different number of draws" % (what, diverged)
+    assert same_bits(cols[:, :3], ocols[:, :3]), "%s: colors differ in bits (rel-L2 %g)" % (what, err)
+
+
+def test_config1_cornell_256_b4_s16(api, oracle, cb_spec, cb_oracle_scene):
+    """BASELINE config 1: Cornell box, 256x256, 4 bounces, 16 spp."""
+    W = H = 256
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.iterations = 4
+    sc.render(16)
+    fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 4, 16)
+    check(sc, fr, "config 1")
+    assert sc.stat("segments") == segs and sc.stat("samples") == W * H * 16
+    assert sc.current_sample == 16
+    # the frozen oracle summary (tests/golden/make_golden.py)
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cb_256x256_b4_s16_summary.npz"))
+    crop = sc.read_colors()[:, :3].reshape(H, W, 3)[96:160, 96:160]
+    assert same_bits(crop, g["crop"]) and segs == int(g["segments"])
+
+
+def test_split_api_equals_fused(api, oracle, cb_spec, cb_oracle_scene):
+    """Scene::generate_rays + Scene::trace_rays per sample (two launches, main.cpp:683-687) ==
+    the fused persistent launch == the oracle; the rays buffer matches too."""
+    W = H = 64
+    a = api.Scene(W, H).load(cb_spec)
+    a.iterations = 4
+    a.render(3, fused=False)
+    b = api.Scene(W, H).load(cb_spec)
+    b.iterations = 4
+    b.render(3, fused=True)
+    fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 4, 3)
+    check(a, fr, "split")
+    check(b, fr, "fused")
+    assert a.current_sample == 3 and b.current_sample == 3
+    rays, orays = a.read_rays(), fr.rays()
+    assert same_bits(rays["P"][:, :3], orays["P"][:, :3]) and same_bits(rays["D"][:, :3], orays["D"][:, :3])
+    # gen_ray alone (prog.cl:384-389)
+    c = api.Scene(W, H).load(cb_spec)
+    c.generate_rays()
+    fr2 = oracle.OracleFrame(W, H)
+    fr2.generate_rays(oracle.make_camera(60, 0, 0, (0, 0, 0), W, H))
+    r2 = c.read_rays()
+    assert same_bits(r2["D"][:, :3], fr2.rays()["D"][:, :3]) and np.array_equal(c.read_rnds(), fr2.rnds())
+
+
+@pytest.mark.parametrize("lds,block", [(1, 256), (0, 256), (0, 64), (0, 512), (0, 1024), (1, 128)])
+def test_variants_identical(api, oracle, cb_spec, cb_oracle_scene, lds, block):
+    W, H = 96, 72
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.set_option("lds_scene", lds)
+    sc.set_option("block", block)
+    sc.iterations = 8
+    sc.render(2)
+    sc.render(2)                                   # continues from current_sample = 2
+    fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 8, 4)
+    check(sc, fr, "lds=%d block=%d" % (lds, block))
+
+
+@pytest.mark.parametrize("W,H,bounces,spp", [(50, 37, 8, 2), (8, 8, 16, 3), (1, 1, 4, 5), (130, 9, 1, 2), (33, 65, 0, 2)])
+def test_ragged_sizes_and_edge_iterations(api, oracle, cb_spec, cb_oracle_scene, W, H, bounces, spp):
+    """Frames that are not multiples of the 8x8 wave tile; iterations = 1 (flat preview,
+    prog.cl:323-325) and 0 (no bounce: black)."""
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.iterations = bounces
+    sc.render(spp)
+    fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, bounces, spp)
+    check(sc, fr, "%dx%d b%d" % (W, H, bounces))
+
+
+def test_tiled_ranks_union_equals_single(api, oracle, cb_spec, cb_oracle_scene):
+    """1-GPU and N-rank images must be bit-identical (seeds and pixel ids are those of
+    the global frame).  All ranks run on this one GPU here."""
+    W, H = 64, 52
+    fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 4, 3)
+    ocols, ornds = fr.colors(), fr.rnds()
+    for world, rb in ((2, 8), (4, 8), (3, 16)):
+        seen = np.zeros(W * H, dtype=bool)
+        for r in range(world):
+            sc = api.Scene(W, H, rank=r, world=world, rows_per_block=rb).load(cb_spec)
+            sc.iterations = 4
+            sc.render(3)
+            ids = sc.local_pixel_ids()
+            assert same_bits(sc.read_colors()[:, :3], ocols[ids, :3])
+            assert np.array_equal(sc.read_rnds(), ornds[ids])
+            seen[ids] = True
+        assert seen.all()
+
+
+def test_mesh_scene_global_memory_path(api, oracle):
+    """A scene too large for LDS staging (displaced grid, ~6k triangles, all four material types
+    reachable) goes through the global-memory traversal; parity bar unchanged."""
+    from opencl_path_tracer_amd import scenes
+    spec = scenes.displaced_grid_mesh(6000)
+    osc = oracle.load_scene(spec)
+    W = H = 64
+    sc = api.Scene(W, H).load(spec)
+    sc.iterations = 6
+    sc.render(3)
+    assert sc.stat("lds_bytes") < 100 * 1024
+    fr, _ = oracle_render(oracle, osc, spec, W, H, 6, 3)
+    check(sc, fr, "mesh")
+
+
+def test_oracle_modes_agree_with_gpu_on_exhaustive_search(api, oracle, cb_spec, cb_oracle_scene):
+    """The GPU computes the exact closest hit with the reference's first-met tie-break; the oracle's
+    exhaustive mode (2) defines exactly that, so this also shows the reference traversal (mode 0)
+    culled no real hit in this configuration."""
+    W = H = 40
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.iterations = 5
+    sc.render(2)
+    fr2, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 5, 2, mode=2)
+    check(sc, fr2, "exhaustive")
+
+
+def test_other_views_and_custom_seeds(api, oracle, cb_spec, cb_oracle_scene):
+    W, H = 48, 40
+    seeds = (np.arange(W * H, dtype=np.int64) * 7919 + 12345) % 2147483646 + 1
+    for fov, yaw, pitch, shift in ((75.0, -63.8, 15.6, (265.0, 162.3, 360.4)), (40.0, 20.0, -10.0, (0, 100, 300))):
+        sc = api.Scene(W, H).load(cb_spec)
+        sc.set_view(fov, yaw, pitch, shift)
+        sc.upload_seeds(seeds.astype(np.int32))
+        sc.iterations = 6
+        sc.render(2)
+        cam = oracle.make_camera(fov, yaw, pitch, shift, W, H)
+        fr = oracle.OracleFrame(W, H, seed_default=False)
+        fr.rnds()[:] = seeds.astype(np.int32)
+        fr.render(cb_oracle_scene, cam, 6, 0, 2, nthreads=16)
+        check(sc, fr, "view %s" % (fov,))
+
+
+def test_sample_zero_resets_accumulator(api, oracle, cb_spec, cb_oracle_scene):
+    """Key events set current_sample = 0 (main.cpp:1046,1102-1130); the kernel then restarts the
+    running mean from black (prog.cl:312-314) while the LCG streams continue."""
+    W = H = 32
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.iterations = 4
+    sc.render(2)
+    sc.current_sample = 0
+    sc.render(2)
+    cam = oracle.make_camera(60, 0, 0, (0, 0, 0), W, H)
+    fr = oracle.OracleFrame(W, H)
+    fr.render(cb_oracle_scene, cam, 4, 0, 2, nthreads=16)
+    fr.render(cb_oracle_scene, cam, 4, 0, 2, nthreads=16)
+    check(sc, fr, "reset")
+
+
+def test_ldr_resolve(api, oracle, cb_spec, cb_oracle_scene):
+    """reinhard_tone_map + sRGB (prog.cl:247-269) of colors == what trace_ray wrote with
+    write_imagef; NaN for black pixels like the reference.  filt_im likewise."""
+    W = H = 48
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.iterations = 4
+    sc.render(4)
+    fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 4, 4)
+    ldr, tex = sc.resolve_ldr(0), fr.tex()
+    assert np.array_equal(np.isnan(ldr), np.isnan(tex))
+    m = ~np.isnan(tex)
+    assert same_bits(ldr[m], tex[m])
+    fr.tex()[:] = 0
+    fr.filt_im(nthreads=4)
+    assert same_bits(sc.resolve_ldr(1), fr.tex())
+
+
+def test_full_size_properties_1080p(api, oracle, cb_spec, cb_oracle_scene):
+    """BASELINE config 2 size (1920x1080, 8 bounces): size-independent properties instead of a full
+    oracle render -- (a) k samples in one launch == k launches of one, (b) the union of two ranks'
+    tiles == the single-context frame, (c) a band of rows equals the oracle bit for bit,
+    (d) a checksum over everything ties (a) and (b) together."""
+    W, H, B = 1920, 1080, 8
+    a = api.Scene(W, H).load(cb_spec)
+    a.iterations = B
+    a.render(3)
+    ca, ra = a.read_colors(), a.read_rnds()
+    b = api.Scene(W, H).load(cb_spec)
+    b.iterations = B
+    for _ in range(3):
+        b.render(1)
+    assert same_bits(ca, b.read_colors()) and np.array_equal(ra, b.read_rnds())
+    del b
+    full_c = np.zeros_like(ca)
+    full_r = np.zeros_like(ra)
+    for r in range(2):
+        t = api.Scene(W, H, rank=r, world=2, rows_per_block=8).load(cb_spec)
+        t.iterations = B
+        t.render(3)
+        ids = t.local_pixel_ids()
+        full_c[ids] = t.read_colors()
+        full_r[ids] = t.read_rnds()
+        del t
+    assert same_bits(ca, full_c) and np.array_equal(ra, full_r)
+    assert np.bitwise_xor.reduce(ra.view(np.uint32)) == np.bitwise_xor.reduce(full_r.view(np.uint32))
+    # oracle on a band of 24 rows through the spheres: render the whole frame's seeds but only
+    # compare rows 300..323 (the oracle renders all pixels; keep it to one sample-set of the band)
+    cam = oracle.make_camera(60, 0, 0, (0, 0, 0), W, H)
+    fr = oracle.OracleFrame(W, H)
+    band = slice(300 * W, 324 * W)
+    # pixels are independent, so render just the band by zeroing the rest of the work:
+    # use a frame of the same width but point the oracle at the band via ids -> simplest is the
+    # full frame at 3 spp on 16 threads (~25 s); acceptable for the one full-size test.
+    fr.render(cb_oracle_scene, cam, B, 0, 3, nthreads=16)
+    assert same_bits(ca[band, :3], fr.colors()[band, :3]) and np.array_equal(ra[band], fr.rnds()[band])
+    assert rel_l2(ca[:, :3], fr.colors()[:, :3]) <= TOL_REL_L2
+    assert same_bits(ca[:, :3], fr.colors()[:, :3])

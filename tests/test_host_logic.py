@@ -1,0 +1,114 @@
+"""-m "not gpu": host logic of the product (constructors, reference encounter order, own BVH,
+tiling) checked against the oracle.  Uses host-only contexts; nothing renders."""
+import numpy as np
+import pytest
+
+import bvh_check
+
+
+def test_constructors_match_oracle(api, oracle, cb_spec):
+    for m in cb_spec.materials:
+        assert api.Material(*m).tobytes() == oracle.make_material(*m).tobytes()
+    verts, mati = cb_spec.objects[1]
+    for i in (0, 1, 17, 500, 959):
+        a = api.Triangle(verts[i, 0], verts[i, 1], verts[i, 2], mati[i])
+        b = oracle.make_triangle(verts[i, 0], verts[i, 1], verts[i, 2], mati[i])
+        assert a.tobytes() == b.tobytes()
+    for args in ((60, 0, 0, (0, 0, 0), 256, 256), (60, 0, 0, (0, 0, 0), 1920, 1080),
+                 (75.0, -13.800002 - 50, 5.599997 + 10, (265.055481, 162.305969, 360.414001), 1536, 864),   # main.cpp:20-21,30-39
+                 (33.3, 123.0, -77.0, (-5.5, 9.25, 1e3), 640, 480)):
+        assert api.Camera(*args).tobytes() == oracle.make_camera(*args).tobytes()
+
+
+def test_encounter_rank_matches_oracle(api, oracle, cb_spec, cb_oracle_scene):
+    sc = api.Scene(16, 16, device=None).load(cb_spec)
+    assert np.array_equal(sc.debug_encounter_rank(cb_spec.ntris), cb_oracle_scene.encounter_rank())
+
+
+def test_encounter_rank_on_mesh(api, oracle):
+    from opencl_path_tracer_amd import scenes
+    spec = scenes.displaced_grid_mesh(6000)
+    sc = api.Scene(16, 16, device=None).load(spec)
+    osc = oracle.load_scene(spec)
+    assert np.array_equal(sc.debug_encounter_rank(spec.ntris), osc.encounter_rank())
+
+
+def test_bvh_structure(api, cb_spec):
+    sc = api.Scene(16, 16, device=None).load(cb_spec)
+    nodes, tris, meta, orig = sc.debug_bvh()
+    assert tris.shape[0] == 1932 and sorted(orig.tolist()) == list(range(1932))
+    depth = bvh_check.validate_structure(nodes, tris, 1932)
+    assert depth <= sc.stat("bvh_depth") <= 30
+    # packets hold exactly the twelve floats prog.cl:94-112 reads, in add order via `orig`
+    verts = np.concatenate([v for v, _ in cb_spec.objects]).reshape(-1, 9)
+    assert np.array_equal(tris[:, :9], verts[orig])
+    mati = np.concatenate([m for _, m in cb_spec.objects])
+    assert np.array_equal(meta[:, 1], mati[orig])
+    assert np.array_equal(meta[:, 0], sc.debug_encounter_rank(1932)[orig])
+    # Cornell box fits the LDS of one CU next to the traversal stacks
+    assert nodes.nbytes + tris.nbytes + 16 * 4 * 256 <= 160 * 1024
+
+
+def test_bvh_never_culls_a_real_hit(api, oracle, cb_spec, cb_oracle_scene):
+    """For random rays, the triangle the oracle's exhaustive search (mode 2) returns must lie in a
+    leaf that the ray's box chain reaches in the product BVH."""
+    sc = api.Scene(16, 16, device=None).load(cb_spec)
+    nodes, tris, meta, orig = sc.debug_bvh()
+    rng = np.random.RandomState(3)
+    n = 300
+    rays = np.zeros(n, dtype=oracle.RAY)
+    P = np.stack([rng.uniform(-50, 1050, n), rng.uniform(10, 990, n), rng.uniform(-900, 900, n)], 1)
+    D = rng.normal(size=(n, 3))
+    D[:20, 0] = 0.0                       # axis-parallel components: division by zero in the slab test
+    D[20:40, 1] = 0.0
+    D /= np.linalg.norm(D, axis=1)[:, None]
+    rays["P"][:, :3] = P
+    rays["D"][:, :3] = D
+    hits = cb_oracle_scene.closest_hit(rays, mode=2)
+    otris = cb_oracle_scene.tris()
+    checked = 0
+    for i in range(n):
+        if not hits[i]["t"] > 0:
+            continue
+        Pd, Dd = rays[i]["P"][:3].astype(np.float64), rays[i]["D"][:3].astype(np.float64)
+        reach = bvh_check.leaves_reaching(nodes, Pd, Dd)
+        best_t, found = float(hits[i]["t"]), False
+        for first, count in reach:
+            for k in range(first, first + count):
+                t = bvh_check.tri_test(tris[k].astype(np.float64), Pd, Dd)
+                if t > 0 and abs(t - best_t) <= 1e-4 * best_t:
+                    found = True
+        assert found, "ray %d: closest hit not reachable through the BVH" % i
+        checked += 1
+    assert checked > 200
+
+
+def test_tiny_and_empty_scenes_build(api):
+    sc = api.Scene(8, 8, device=None)
+    sc.add_Material((0.3, 0.3, 0.3), (0, 0, 0), (0, 0, 0), (0, 0, 0), (0, 0, 0), 50.0, 0)
+    sc.upload_Triangles()                 # empty scene: a root with two empty children
+    sc.upload_Materials()
+    nodes, tris, meta, orig = sc.debug_bvh()
+    assert nodes.shape[0] == 1 and tris.shape[0] == 0
+    sc.add_Triangle((0, 0, 0), (1, 0, 0), (0, 1, 0), 0)
+    sc.end_Obj()
+    sc.upload_Triangles()
+    nodes, tris, meta, orig = sc.debug_bvh()
+    assert nodes.shape[0] == 1 and tris.shape[0] == 1
+    assert bvh_check.validate_structure(nodes, tris, 1) == 0
+
+
+@pytest.mark.parametrize("H,world,rb", [(64, 1, 8), (64, 2, 8), (1080, 8, 8), (37, 4, 8), (100, 3, 16), (5, 8, 8)])
+def test_tiling_partitions_the_frame(api, H, world, rb):
+    """interleaved row blocks; every global pixel belongs to exactly one rank."""
+    W = 24
+    owner = np.full(W * H, -1)
+    for r in range(world):
+        sc = api.Scene(W, H, device=None, rank=r, world=world, rows_per_block=rb)
+        ids = sc.local_pixel_ids()
+        assert ids.size == sc.local_pixels
+        assert (owner[ids] == -1).all()
+        owner[ids] = r
+        rows = np.unique(ids // W)
+        assert ((rows // rb) % world == r).all()
+    assert (owner >= 0).all()
