@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the path-tracing hot path on MI355X.
+
+Metric (BASELINE.json): Msamples/s, whole job, at 1920x1080, 8 bounces, Cornell box
+(config 2: 1,024 spp at the default --steps 64 x 16 spp).  A sample is one camera path of up
+to 8 segments.  One "step" = one pass of the hot path (gen_ray + trace_ray, fused) taking
+--spp-per-step samples of every pixel of the frame.
+
+N > 1 (launched by torch.distributed.run, one process per GPU): the frame is tiled in
+interleaved 8-row blocks over the ranks (strong scaling: the frame is fixed), every rank
+renders its own pixels with no communication, and the timed region ends with ONE RCCL
+all-gather of the radiance slabs + de-interleave on every rank.
+
+The timed region starts with scene, seeds and framebuffer resident in HBM and is bracketed by
+barrier + torch.cuda.synchronize(); the time is the max over ranks.  Rank 0 prints ONE JSON line.
+
+Extra objects: "roofline" (algorithmic HBM bytes of SURVEY 8(d) / HIP-event kernel time vs the
+8 TB/s peak) and "cpu_baseline" (the CPU oracle = port of the reference path, timed on this
+host's cores on a bounded sample of the same workload; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: libptamd.so must bind to the HIP runtime torch loaded)
+import torch.distributed as dist  # noqa: E402
+
+from opencl_path_tracer_amd import api, scenes  # noqa: E402
+
+WIDTH, HEIGHT, BOUNCES = 1920, 1080, 8
+ROWS_PER_BLOCK = 8
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
+BYTES_PER_SEGMENT = 200.0        # 92 B state R + 92 B W + 8 B hit W + 8 B R
+BYTES_PER_SAMPLE = 32.0          # colors 16 B R + 16 B W
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--bounces", type=int, default=BOUNCES)
+    ap.add_argument("--lds-scene", type=int, default=-1, help="-1 library default, 0/1 force")
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(width, height, bounces, target_s):
+    """The oracle (C port of prog.cl's gen_ray/trace_ray incl. the reference's own kd-tree
+    traversal) on all host cores, bounded sample of the same workload."""
+    from oracle import oracle_py as O
+    spec = scenes.cornell_box()
+    osc = O.load_scene(spec)
+    cam = O.make_camera(spec.fov, spec.yaw, spec.pitch, spec.shift, width, height)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # calibrate on a 1/16-area strip: rows [0, height/16) via a short frame of the same width
+    fr = O.OracleFrame(width, height)
+    t0 = time.time()
+    # one sample of the whole frame is the smallest unit that keeps the workload's pixel mix
+    fr.render(osc, cam, bounces, 0, 1, mode=0, nthreads=cores)
+    t1 = time.time() - t0
+    spp = 1
+    extra = int(max(0, min(15, (target_s - t1) // max(t1, 1e-3))))
+    if extra > 0:
+        t0 = time.time()
+        fr.render(osc, cam, bounces, 1, extra, mode=0, nthreads=cores)
+        t1 += time.time() - t0
+        spp += extra
+    samples = width * height * spp
+    return {"value": samples / t1 / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "Cornell box %dx%d, %d bounces, %d spp (full frame), oracle/pt_oracle.c mode 0, %.1f s" % (width, height, bounces, spp, t1)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H, B = args.width, args.height, args.bounces
+    spec = scenes.cornell_box()
+    sc = api.Scene(W, H, device=local_rank, rank=rank, world=world, rows_per_block=ROWS_PER_BLOCK).load(spec)
+    sc.iterations = B
+    if args.lds_scene >= 0:
+        sc.set_option("lds_scene", args.lds_scene)
+    if args.block:
+        sc.set_option("block", args.block)
+    sc.set_option("timing", 1)
+
+    # device memory and stream are torch's: the radiance slab is a torch tensor so that RCCL
+    # (torch.distributed) can gather it; padded to the largest rank's pixel count.
+    from opencl_path_tracer_amd.distributed import TileMap, exchange_frame
+    tmap = TileMap(W, H, world, ROWS_PER_BLOCK)
+    npix = sc.local_pixels
+    assert npix == tmap.count(rank)
+    slab = torch.zeros((tmap.max_count, 4), dtype=torch.float32, device=dev)
+    rnds = torch.zeros((tmap.max_count,), dtype=torch.int32, device=dev)
+    sc.bind_framebuffer(slab.data_ptr(), rnds.data_ptr())
+    stream = torch.cuda.current_stream(dev)
+    sc.set_stream(stream.cuda_stream)
+    gathered = torch.empty((world * tmap.max_count, 4), dtype=torch.float32, device=dev) if world > 1 else None
+    frame = torch.empty((W * H + 1, 4), dtype=torch.float32, device=dev) if world > 1 else None
+    scatter_index = tmap.gather_index(dev) if world > 1 else None
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def exchange():
+        return exchange_frame(slab, tmap, scatter_index, gathered, frame)
+
+    # ---- warmup (untimed)
+    for _ in range(args.warmup):
+        sc.render(args.spp_per_step)
+    exchange()
+    sync_all()
+    sc.current_sample = 0
+    sc.seed_default()
+    sc.set_option("reset_stats", 1)
+
+    # ---- timed region: exactly K steps + the final exchange
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sc.render(args.spp_per_step)
+    out = exchange()
+    sync_all()
+    dt = time.perf_counter() - t0
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    stats = torch.tensor([sc.stat("segments"), sc.stat("samples"), sc.stat("kernel_ms"), sc.stat("kernel_launches")],
+                         dtype=torch.float64, device=dev)
+    kmax = stats[2:3].clone()
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    segs, samples, kms_sum, launches = [float(x) for x in stats.tolist()]
+    total_spp = args.steps * args.spp_per_step
+    assert samples == float(W) * H * total_spp, (samples, W * H * total_spp)
+    checksum = float(out[:, :3].double().sum().item())
+
+    if rank == 0:
+        dbar = segs / samples
+        value = samples / dt / 1e6
+        # dominant kernel: k_render.  Algorithmic bytes per launch / mean launch time.
+        launches_per_rank = launches / world
+        bytes_per_launch = (BYTES_PER_SAMPLE + BYTES_PER_SEGMENT * dbar) * (samples / launches)
+        mean_launch_ms = (kms_sum / world) / launches_per_rank
+        achieved = bytes_per_launch / (mean_launch_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("config") == "%dx%d_b%d_spp%d" % (W, H, B, args.spp_per_step):
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Msamples/s (whole node) at 1920x1080, 8-bounce Cornell box",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Cornell box (12 wall/lamp triangles + 2 tessellated spheres = 1,932 triangles), "
+                                   "%dx%d, %d bounces, %d spp (%d steps x %d spp)" % (W, H, B, total_spp, args.steps, args.spp_per_step),
+                       "parallelism": "tiles%d" % world, "rows_per_block": ROWS_PER_BLOCK,
+                       "kernel": "k_render (fused gen_ray+trace_ray, persistent per pixel)"},
+            "mean_path_segments": dbar, "msegments_per_s": segs / dt / 1e6, "radiance_checksum": checksum,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_render", "mean_launch_ms": mean_launch_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(W, H, B, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

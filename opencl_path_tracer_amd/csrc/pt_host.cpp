@@ -75,8 +75,11 @@ struct pt_context {
     // ---- options
     int variant = 0;
     int block = 256;
-    int lds_scene = 1;
+    int lds_scene = 0;   // staging the whole scene in LDS costs occupancy (1 block/CU); measured slower, off by default
     int timing = 0;
+    int count_work = 0;
+    int min_waves = 4;    // k_render at 128 VGPRs (4 waves/SIMD) measured fastest
+    int bvh_policy = 0;   // 0 auto (SAH termination; LDS fit when lds_scene is on), 1 SAH termination, 2 leaves of <= 4, 3 leaves of <= 8
 
     // ---- statistics
     std::vector<EventPair> events;
@@ -375,9 +378,10 @@ int build_and_pack(pt_context* ctx) {
         return sizeof(Node64) * b.nodes.size() + sizeof(TriPacket) * b.order.size() + (size_t)entries * 4 * 256;
     };
     BvhBuilder bld;
-    int rc = build_attempt(ctx, bld, prims, 4, false);
+    int rc = ctx->bvh_policy <= 1 ? build_attempt(ctx, bld, prims, 4, false)
+                                  : build_attempt(ctx, bld, prims, ctx->bvh_policy == 2 ? 4 : 8, true);
     if (rc != PT_OK) return rc;
-    if (footprint(bld) > lds_budget && sizeof(TriPacket) * prims.size() < lds_budget) {
+    if (ctx->bvh_policy == 0 && ctx->lds_scene && footprint(bld) > lds_budget && sizeof(TriPacket) * prims.size() < lds_budget) {
         const int tries[2][2] = {{4, 1}, {8, 1}};
         for (auto& t : tries) {
             BvhBuilder alt;
@@ -737,13 +741,16 @@ int pt_upload_seeds(pt_context* ctx, const int32_t* seeds, int64_t n) {
 static int launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc) {
     lc->block = ctx->block;
     lc->lds_bytes = mega_lds_bytes(p, ctx->block);
+    lc->count_work = ctx->count_work != 0;
+    lc->min_waves = ctx->min_waves;
     ctx->last_lds_bytes = lc->lds_bytes;
     return PT_OK;
 }
 
 static void decide_lds_scene(const pt_context* ctx, RenderParams* p) {
     size_t scene = sizeof(Node64) * ctx->nodes.size() + sizeof(TriPacket) * ctx->orig.size();
-    size_t stack = (size_t)p->stack_entries * 4 * (size_t)ctx->block;
+    const bool s16 = ctx->nodes.size() <= 32768 && ctx->orig.size() <= 4096;
+    size_t stack = (size_t)p->stack_entries * (s16 ? 2 : 4) * (size_t)ctx->block + 16;
     p->lds_scene = (ctx->lds_scene && scene + stack <= (size_t)mega_max_lds_scene_bytes()) ? 1 : 0;
 }
 
@@ -915,9 +922,22 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return fail(ctx, PT_EINVAL, "block must be 64..1024, power of two");
         ctx->block = (int)value;
     } else if (k == "lds_scene") {
+        if ((value ? 1 : 0) != ctx->lds_scene && ctx->bvh_policy == 0 && ctx->tris_uploaded) {
+            ctx->lds_scene = value ? 1 : 0;          // the automatic BVH policy depends on it: rebuild
+            int rc = pt_upload_triangles(ctx);
+            if (rc != PT_OK) return rc;
+        }
         ctx->lds_scene = value ? 1 : 0;
     } else if (k == "timing") {
         ctx->timing = value ? 1 : 0;
+    } else if (k == "count_work") {
+        ctx->count_work = value ? 1 : 0;
+    } else if (k == "min_waves") {
+        ctx->min_waves = (int)value;
+    } else if (k == "bvh_policy") {
+        if (value < 0 || value > 3) return fail(ctx, PT_EINVAL, "bvh_policy must be 0..3");
+        ctx->bvh_policy = (int)value;
+        ctx->tris_uploaded = false;
     } else if (k == "reset_stats") {
         if (ctx->has_device) {
             PT_HIP(ctx, hipSetDevice(ctx->device));
@@ -950,11 +970,11 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out) {
         *out = ctx->kernel_ms_acc;
         return PT_OK;
     }
-    if (k == "segments" || k == "samples") {
+    if (k == "segments" || k == "samples" || k == "node_visits" || k == "tri_tests") {
         unsigned long long h[8];
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         PT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
-        *out = (double)h[k == "segments" ? 0 : 1];
+        *out = (double)h[k == "segments" ? 0 : k == "samples" ? 1 : k == "node_visits" ? 2 : 3];
         return PT_OK;
     }
     return fail(ctx, PT_EINVAL, "unknown stat: " + k);

@@ -65,6 +65,8 @@ struct RenderParams {
 struct LaunchConfig {
     int block = 256;
     size_t lds_bytes = 0;
+    int min_waves = 1;         // __launch_bounds__ second argument (waves per SIMD the allocator must allow)
+    bool count_work = false;   // also count node visits / triangle tests into stats[2], stats[3]
 };
 
 // launchers implemented in pt_kernels.hip; all asynchronous on `stream`

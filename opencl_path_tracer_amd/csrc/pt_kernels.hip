@@ -190,84 +190,124 @@ struct SceneView {
     const TriMeta* meta;   // global
 };
 
-// prog.cl:94-112 on one packet; returns t (> 0) or -1
-PT_DEV float tri_test(const float4 a, const float4 b, const float4 c, f3 P, f3 Vd) {
+// prog.cl:94-112 on one packet; returns t (> 0) or -1.  `limit` is the current closest t: a
+// triangle whose t is clearly larger can neither win nor tie, so it is dropped before the exact
+// (IEEE-divide) evaluation.  Both early-outs are conservative: whatever the exact test would
+// accept with t <= best_t passes them (t > 0 needs num and den of the same non-zero sign; the
+// reciprocal estimate is within 2 ulp and the margin is 16 ulp).
+PT_DEV float tri_test(const float4 a, const float4 b, const float4 c, f3 P, f3 Vd, float limit) {
     const f3 r1 = mk(a.x, a.y, a.z), r2 = mk(a.w, b.x, b.y), r3 = mk(b.z, b.w, c.x), N = mk(c.y, c.z, c.w);
-    const float t = dot3(r1 - P, N) / dot3(Vd, N);
-    const f3 pt = madd(Vd, t, P);
-    const float c1 = dot3(cross3(r2 - r1, pt - r1), N);
-    const float c2 = dot3(cross3(r3 - r2, pt - r2), N);
-    const float c3 = dot3(cross3(r1 - r3, pt - r3), N);
-    const bool ok = !(t < 0.0f) && (c1 >= 0.0f) && (c2 >= 0.0f) && (c3 >= 0.0f) && (t > 0.0f);
-    return ok ? t : -1.0f;
+    const float num = dot3(r1 - P, N), den = dot3(Vd, N);
+    float res = -1.0f;
+    const bool same_sign = (num > 0.0f && den > 0.0f) || (num < 0.0f && den < 0.0f);
+    if (same_sign && num * __builtin_amdgcn_rcpf(den) <= limit) {
+        const float t = num / den;
+        const f3 pt = madd(Vd, t, P);
+        const float c1 = dot3(cross3(r2 - r1, pt - r1), N);
+        const float c2 = dot3(cross3(r3 - r2, pt - r2), N);
+        const float c3 = dot3(cross3(r1 - r3, pt - r3), N);
+        const bool ok = !(t < 0.0f) && (c1 >= 0.0f) && (c2 >= 0.0f) && (c3 >= 0.0f) && (t > 0.0f);
+        res = ok ? t : -1.0f;
+    }
+    return res;
 }
+
+// Per-lane traversal stack in LDS, laid out [entry][lane] (consecutive lanes -> consecutive
+// banks).  Small scenes (the ones that are LDS-resident) use 16-bit entries so that 16 waves per
+// CU fit next to the staged scene: interior index < 2^15, or 0x8000 | (first << 3 | count-1).
+template <class T>
+struct LaneStack {
+    T* base;        // already offset by the lane
+    int stride;     // entries are `stride` elements apart
+    PT_DEV void put(int sp, int ref) const {
+        if (sizeof(T) == 2) base[sp * stride] = (T)(ref >= 0 ? ref : (0x8000 | (~ref)));
+        else base[sp * stride] = (T)ref;
+    }
+    PT_DEV int get(int sp) const {
+        if (sizeof(T) == 2) {
+            const int e = (int)base[sp * stride];
+            return (e & 0x8000) ? ~(e & 0x7fff) : e;
+        }
+        return (int)base[sp * stride];
+    }
+};
+
+struct WorkCount {
+    unsigned nodes, tris;
+};
 
 // closest hit over the whole scene; ties in t go to the lower encounter rank (the triangle
 // the reference's traversal, prog.cl:113-184, meets first).  Returns packed triangle index or -1.
-template <bool LDS_SCENE>
-PT_DEV int closest_hit(const SceneView& sv, f3 P, f3 D, unsigned* stk, const int stride, float* t_out) {
+template <class StackT, bool COUNT>
+PT_DEV int closest_hit(const SceneView& sv, f3 P, f3 D, const LaneStack<StackT> stk, float* t_out, WorkCount* wc) {
     const float kWiden = 1.0000005f;   // > 4 ulp: covers rcp + sub + mul rounding of the slab test
     const f3 inv = mk(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
     float best_t = __builtin_inff();
     int best = -1;
     int sp = 0;
-    int cur = 0;  // root is always an interior node
-    for (;;) {
-        // ---- interior node: test both children
-        const float4 qx = sv.nodes[cur * 4 + 0];
-        const float4 qy = sv.nodes[cur * 4 + 1];
-        const float4 qz = sv.nodes[cur * 4 + 2];
-        const float4 qr = sv.nodes[cur * 4 + 3];
-        const float lx0 = (qx.x - P.x) * inv.x, lx1 = (qx.y - P.x) * inv.x;
-        const float rx0 = (qx.z - P.x) * inv.x, rx1 = (qx.w - P.x) * inv.x;
-        const float ly0 = (qy.x - P.y) * inv.y, ly1 = (qy.y - P.y) * inv.y;
-        const float ry0 = (qy.z - P.y) * inv.y, ry1 = (qy.w - P.y) * inv.y;
-        const float lz0 = (qz.x - P.z) * inv.z, lz1 = (qz.y - P.z) * inv.z;
-        const float rz0 = (qz.z - P.z) * inv.z, rz1 = (qz.w - P.z) * inv.z;
-        const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
-        const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1)) * kWiden;
-        const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
-        const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1)) * kWiden;
-        const float lim = best_t * kWiden;
-        const bool hl = (lf >= ln) && (lf >= 0.0f) && (ln <= lim);
-        const bool hr = (rf >= rn) && (rf >= 0.0f) && (rn <= lim);
-        const int li = __float_as_int(qr.x), ri = __float_as_int(qr.y);
-        int next;
-        if (hl && hr) {
-            const bool lfirst = ln <= rn;
-            next = lfirst ? li : ri;
-            stk[sp * stride] = (unsigned)(lfirst ? ri : li);
-            ++sp;
-        } else if (hl) {
-            next = li;
-        } else if (hr) {
-            next = ri;
-        } else {
-            if (sp == 0) break;
-            --sp;
-            next = (int)stk[sp * stride];
+    // while-while traversal: every lane first descends through interior nodes until it holds a
+    // leaf (or has finished), then all lanes holding leaves intersect them; repeat.
+    const int kDone = 0x7fffffff;
+    int cur = 0;  // >= 0: interior node index (the root always is one); < 0: leaf reference
+    while (cur != kDone) {
+        while (cur >= 0 && cur != kDone) {
+            const float4 qx = sv.nodes[cur * 4 + 0];
+            const float4 qy = sv.nodes[cur * 4 + 1];
+            const float4 qz = sv.nodes[cur * 4 + 2];
+            const float4 qr = sv.nodes[cur * 4 + 3];
+            if (COUNT) wc->nodes++;
+            const float lx0 = (qx.x - P.x) * inv.x, lx1 = (qx.y - P.x) * inv.x;
+            const float rx0 = (qx.z - P.x) * inv.x, rx1 = (qx.w - P.x) * inv.x;
+            const float ly0 = (qy.x - P.y) * inv.y, ly1 = (qy.y - P.y) * inv.y;
+            const float ry0 = (qy.z - P.y) * inv.y, ry1 = (qy.w - P.y) * inv.y;
+            const float lz0 = (qz.x - P.z) * inv.z, lz1 = (qz.y - P.z) * inv.z;
+            const float rz0 = (qz.z - P.z) * inv.z, rz1 = (qz.w - P.z) * inv.z;
+            const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
+            const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1)) * kWiden;
+            const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
+            const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1)) * kWiden;
+            const float lim = best_t * kWiden;
+            const bool hl = (lf >= ln) && (lf >= 0.0f) && (ln <= lim);
+            const bool hr = (rf >= rn) && (rf >= 0.0f) && (rn <= lim);
+            const int li = __float_as_int(qr.x), ri = __float_as_int(qr.y);
+            if (hl && hr) {
+                const bool lfirst = ln <= rn;
+                cur = lfirst ? li : ri;
+                stk.put(sp, lfirst ? ri : li);
+                ++sp;
+            } else if (hl) {
+                cur = li;
+            } else if (hr) {
+                cur = ri;
+            } else if (sp == 0) {
+                cur = kDone;
+            } else {
+                --sp;
+                cur = stk.get(sp);
+            }
         }
-        // ---- leaves: intersect, then pop, until an interior node is current again
-        bool done = false;
-        while (next < 0) {
-            const int v = ~next;
+        while (cur < 0) {
+            const int v = ~cur;
             const int first = v >> 3, count = (v & 7) + 1;
+            const float limit = best_t * 1.000002f;
             for (int k = 0; k < count; ++k) {
                 const int ti = first + k;
                 const float4 a = sv.tris[ti * 3 + 0], b = sv.tris[ti * 3 + 1], c = sv.tris[ti * 3 + 2];
-                const float t = tri_test(a, b, c, P, D);
+                if (COUNT) wc->tris++;
+                const float t = tri_test(a, b, c, P, D, limit);
                 if (t > 0.0f) {
                     bool better = t < best_t;
                     if (t == best_t && best >= 0) better = sv.meta[ti].rank < sv.meta[best].rank;
                     if (better) { best_t = t; best = ti; }
                 }
             }
-            if (sp == 0) { done = true; break; }
-            --sp;
-            next = (int)stk[sp * stride];
+            if (sp == 0) {
+                cur = kDone;
+            } else {
+                --sp;
+                cur = stk.get(sp);
+            }
         }
-        if (done) break;
-        cur = next;
     }
     *t_out = best_t;
     return best;
@@ -349,50 +389,56 @@ PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, c
     const int type = m->type;
     if (p.iterations == 1) color = ldf3(m->kd) + ldf3(m->emission);         // prog.cl:323-325
     if (dot3(rD, N) > 0.0f) N = -N;                                         // prog.cl:326-328
-    if (type == 0) {                                                        // prog.cl:329-340
-        const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
-        const RayPD nr = new_ray_diffuse(hp, N, rnd1, rnd2);
-        const f3 nP = nr.P, nD = nr.D;
-        const float idiff = max0(dot3(nD, N));
-        fL = fL * (ldf3(m->kd) * idiff);
-        const f3 view = normalize3(ldf3(p.cam.eye) - hp);
-        const f3 halfway = normalize3(view + nD);
-        const float ispec = max0(dot3(N, halfway));
-        fB = fB * (ldf3(m->ks) * spec_pow(ispec, m->shininess));
-        rP = nP;
-        rD = nD;
-    } else if (type == 1) {                                                 // prog.cl:341-345
-        const f3 oldD = rD;
-        const RayPD nr = new_ray_specular(hp, N, oldD);
-        fS = fS * fresnel(ldf3(m->F0), N, oldD);
-        rP = nr.P;
-        rD = nr.D;
-    } else if (type == 2) {                                                 // prog.cl:346-357
-        const f3 oldD = rD;
-        const float rnd = lcg_rand(seed);
-        const f3 F0 = ldf3(m->F0);
-        bool flipped;
-        const RayPD nr = new_ray_refractive(hp, N, F0, m->n, oldD, inside, rnd, &flipped);
-        const f3 F = fresnel(F0, N, oldD);
-        const float prob = ((F.x + F.y) + F.z) / 3.0f;
-        if (flipped) {
-            const float k = 1.0f / (1.0f - prob);
-            fR = (fR * mk(1.0f - F.x, 1.0f - F.y, 1.0f - F.z)) * k;
-        } else {
-            const float k = 1.0f / prob;
-            fR = (fR * F) * k;
-        }
-        inside = inside != flipped;
-        rP = nr.P;
-        rD = nr.D;
-    } else if (type == 3) {                                                 // prog.cl:358-366
+    if (type == 0 || type == 3) {
+        // diffuse (prog.cl:329-340) and emitter (prog.cl:358-366) both continue with a cosine-
+        // sampled ray drawn from two LCG values; the emitter's cosine uses the OLD direction.
         const float inten = max0(dot3(-rD, N));
         const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
         const RayPD nr = new_ray_diffuse(hp, N, rnd1, rnd2);
-        const f3 e = ((ldf3(m->emission) * (fL + fB)) * fS) * fR;
-        color = madd(e, inten, color);
+        if (type == 0) {
+            const float idiff = max0(dot3(nr.D, N));
+            fL = fL * (ldf3(m->kd) * idiff);
+            const f3 view = normalize3(ldf3(p.cam.eye) - hp);
+            const f3 halfway = normalize3(view + nr.D);
+            const float ispec = max0(dot3(N, halfway));
+            fB = fB * (ldf3(m->ks) * spec_pow(ispec, m->shininess));
+        } else {
+            const f3 e = ((ldf3(m->emission) * (fL + fB)) * fS) * fR;
+            color = madd(e, inten, color);
+        }
         rP = nr.P;
         rD = nr.D;
+    } else if (type == 1 || type == 2) {
+        // mirror (prog.cl:341-345) and dielectric (prog.cl:346-357, 228-245) share the Fresnel
+        // term and the mirror direction; the dielectric may pick the refracted direction instead.
+        const f3 oldD = rD;
+        const f3 F0 = ldf3(m->F0);
+        const f3 F = fresnel(F0, N, oldD);
+        f3 dsel = oldD - (N * dot3(N, oldD)) * 2.0f;
+        bool refr = false;
+        if (type == 2) {
+            float n = m->n;
+            if (inside) n = 1.0f / n;
+            const float rnd = lcg_rand(seed);
+            const float cosa = dot3(-oldD, N);
+            const float disc = 1.0f - (fmaf_(-cosa, cosa, 1.0f) / n) / n;
+            const float prob = ((F.x + F.y) + F.z) / 3.0f;
+            refr = disc > 0.0f && rnd > prob;
+            if (refr) {
+                const f3 dn = mk(oldD.x / n, oldD.y / n, oldD.z / n);
+                dsel = madd(N, cosa / n - __builtin_sqrtf(disc), dn);
+                const float k = 1.0f / (1.0f - prob);
+                fR = (fR * mk(1.0f - F.x, 1.0f - F.y, 1.0f - F.z)) * k;
+                inside = !inside;
+            } else {
+                const float k = 1.0f / prob;
+                fR = (fR * F) * k;
+            }
+        } else {
+            fS = fS * F;
+        }
+        rD = normalize3(dsel);
+        rP = madd(N, refr ? -0.001f : 0.001f, hp);
     }
     // any other type: the ray is left unchanged and the loop hits the same surface again
 }
@@ -434,15 +480,20 @@ __global__ void __launch_bounds__(256) k_gen_ray(RenderParams p) {
 
 // The render kernel.  SPLIT = true: trace_ray alone (prog.cl:292-381), the ray comes from the
 // rays buffer and one sample is taken; SPLIT = false: nsamples x (gen_ray + trace_ray).
-template <bool SPLIT, bool LDS_SCENE, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_render(RenderParams p) {
-    unsigned* stk = reinterpret_cast<unsigned*>(pt_lds_raw) + threadIdx.x;   // [entry][lane]
+template <bool SPLIT, bool LDS_SCENE, int BLOCK, class StackT, bool COUNT, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
+    LaneStack<StackT> stk;
+    stk.base = reinterpret_cast<StackT*>(pt_lds_raw) + threadIdx.x;          // [entry][lane]
+    stk.stride = BLOCK;
+    WorkCount wc;
+    wc.nodes = 0;
+    wc.tris = 0;
     SceneView sv;
     sv.nodes = p.nodes;
     sv.tris = p.tris;
     sv.meta = p.meta;
     if (LDS_SCENE) {
-        float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + (size_t)p.stack_entries * 4 * BLOCK);
+        float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + (size_t)p.stack_entries * sizeof(StackT) * BLOCK);
         float4* lds_tris = lds_nodes + p.n_nodes * 4;
         stage_scene(p, lds_nodes, lds_tris);
         sv.nodes = lds_nodes;
@@ -488,7 +539,7 @@ __global__ void __launch_bounds__(BLOCK) k_render(RenderParams p) {
             bool finished = true;
             if (bounce < p.iterations) {
                 float t;
-                const int ti = closest_hit<LDS_SCENE>(sv, rP, rD, stk, BLOCK, &t);
+                const int ti = closest_hit<StackT, COUNT>(sv, rP, rD, stk, &t, &wc);
                 ++segs;
                 if (ti >= 0) {
                     shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, ti, t);
@@ -513,6 +564,13 @@ __global__ void __launch_bounds__(BLOCK) k_render(RenderParams p) {
     }
     segs = wave_sum(segs);
     samples = wave_sum(samples);
+    if (COUNT) {
+        const unsigned long long wn = wave_sum((unsigned long long)wc.nodes), wt = wave_sum((unsigned long long)wc.tris);
+        if ((threadIdx.x & 63) == 0 && p.stats) {
+            atomicAdd(&p.stats[2], wn);
+            atomicAdd(&p.stats[3], wt);
+        }
+    }
     if ((threadIdx.x & 63) == 0 && p.stats) {
         atomicAdd(&p.stats[0], segs);
         atomicAdd(&p.stats[1], samples);
@@ -584,8 +642,11 @@ static inline int n_waves(const RenderParams& p) {
 
 int mega_max_lds_scene_bytes() { return 160 * 1024; }
 
+static inline bool stack16_ok(const RenderParams& p) { return p.lds_scene && p.n_nodes <= 32768 && p.n_tris <= 4096; }
+
 size_t mega_lds_bytes(const RenderParams& p, int block) {
-    size_t b = (size_t)p.stack_entries * 4 * (size_t)block;
+    size_t b = (size_t)p.stack_entries * (stack16_ok(p) ? 2 : 4) * (size_t)block;
+    b = (b + 15) & ~(size_t)15;
     if (p.lds_scene) b += (size_t)p.n_nodes * 64 + (size_t)p.n_tris * 48;
     return b;
 }
@@ -598,16 +659,17 @@ hipError_t launch_gen_ray(const RenderParams& p, const LaunchConfig&, hipStream_
     return hipGetLastError();
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool COUNT>
 static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
     const int waves = n_waves(p);
     if (waves == 0) return hipSuccess;
     const int wpb = lc.block / 64;
     const int blocks = (waves + wpb - 1) / wpb;
     const size_t lds = lc.lds_bytes;
-#define PT_LAUNCH(LDS, B)                                                                          \
+#define PT_LAUNCH(LDS, B, ST) PT_LAUNCH_W(LDS, B, ST, 1)
+#define PT_LAUNCH_W(LDS, B, ST, MW)                                                                \
     do {                                                                                           \
-        auto kern = k_render<SPLIT, LDS, B>;                                                       \
+        auto kern = k_render<SPLIT, LDS, B, ST, COUNT, MW>;                                        \
         if (lds > 64 * 1024) {                                                                     \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                         \
@@ -615,29 +677,48 @@ static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc,
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(B), lds, stream, p);                           \
         return hipGetLastError();                                                                  \
     } while (0)
-    if (p.lds_scene) {
+    if (p.lds_scene && stack16_ok(p)) {
         switch (lc.block) {
-        case 64: PT_LAUNCH(true, 64);
-        case 128: PT_LAUNCH(true, 128);
-        case 256: PT_LAUNCH(true, 256);
-        case 512: PT_LAUNCH(true, 512);
-        case 1024: PT_LAUNCH(true, 1024);
+        case 64: PT_LAUNCH(true, 64, unsigned short);
+        case 128: PT_LAUNCH(true, 128, unsigned short);
+        case 256: PT_LAUNCH(true, 256, unsigned short);
+        case 512: PT_LAUNCH(true, 512, unsigned short);
+        case 1024: PT_LAUNCH(true, 1024, unsigned short);
+        }
+    } else if (p.lds_scene) {
+        switch (lc.block) {
+        case 64: PT_LAUNCH(true, 64, unsigned);
+        case 128: PT_LAUNCH(true, 128, unsigned);
+        case 256: PT_LAUNCH(true, 256, unsigned);
+        case 512: PT_LAUNCH(true, 512, unsigned);
+        case 1024: PT_LAUNCH(true, 1024, unsigned);
         }
     } else {
+        if (!SPLIT && !COUNT && lc.block == 256 && lc.min_waves > 1) {      // occupancy experiments
+            switch (lc.min_waves) {
+            case 4: PT_LAUNCH_W(false, 256, unsigned, 4);
+            case 5: PT_LAUNCH_W(false, 256, unsigned, 5);
+            case 6: PT_LAUNCH_W(false, 256, unsigned, 6);
+            case 8: PT_LAUNCH_W(false, 256, unsigned, 8);
+            }
+        }
         switch (lc.block) {
-        case 64: PT_LAUNCH(false, 64);
-        case 128: PT_LAUNCH(false, 128);
-        case 256: PT_LAUNCH(false, 256);
-        case 512: PT_LAUNCH(false, 512);
-        case 1024: PT_LAUNCH(false, 1024);
+        case 64: PT_LAUNCH(false, 64, unsigned);
+        case 128: PT_LAUNCH(false, 128, unsigned);
+        case 256: PT_LAUNCH(false, 256, unsigned);
+        case 512: PT_LAUNCH(false, 512, unsigned);
+        case 1024: PT_LAUNCH(false, 1024, unsigned);
         }
     }
 #undef PT_LAUNCH
+#undef PT_LAUNCH_W
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) { return launch_render_t<true>(p, lc, stream); }
-hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) { return launch_render_t<false>(p, lc, stream); }
+hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) { return launch_render_t<true, false>(p, lc, stream); }
+hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
+    return lc.count_work ? launch_render_t<false, true>(p, lc, stream) : launch_render_t<false, false>(p, lc, stream);
+}
 
 hipError_t launch_resolve_reinhard(const float4* colors, float4* out, int64_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;

@@ -45,8 +45,13 @@ def test_bvh_structure(api, cb_spec):
     mati = np.concatenate([m for _, m in cb_spec.objects])
     assert np.array_equal(meta[:, 1], mati[orig])
     assert np.array_equal(meta[:, 0], sc.debug_encounter_rank(1932)[orig])
-    # Cornell box fits the LDS of one CU next to the traversal stacks
-    assert nodes.nbytes + tris.nbytes + 16 * 4 * 256 <= 160 * 1024
+    # with LDS staging requested, the builder picks fatter leaves so that the Cornell box fits the
+    # LDS of one CU next to the traversal stacks
+    sc.set_option("lds_scene", 1)
+    nodes2, tris2, _, orig2 = sc.debug_bvh()
+    assert sorted(orig2.tolist()) == list(range(1932))
+    bvh_check.validate_structure(nodes2, tris2, 1932)
+    assert nodes2.nbytes + tris2.nbytes + 16 * 4 * 256 <= 160 * 1024 < nodes.nbytes + tris.nbytes + 16 * 4 * 256
 
 
 def test_bvh_never_culls_a_real_hit(api, oracle, cb_spec, cb_oracle_scene):
