@@ -241,3 +241,33 @@ def test_full_size_properties_1080p(api, oracle, cb_spec, cb_oracle_scene):
     assert same_bits(ca[band, :3], fr.colors()[band, :3]) and np.array_equal(ra[band], fr.rnds()[band])
     assert rel_l2(ca[:, :3], fr.colors()[:, :3]) <= TOL_REL_L2
     assert same_bits(ca[:, :3], fr.colors()[:, :3])
+
+
+def test_cpp_dropin_host_program(oracle):
+    """tests/cpp/dropin_main.cpp is written like the reference's onInitialization()/onIdle()
+    against include/pt_scene.hpp (the C++ mirror of class Scene).  Its colors checksum must equal
+    the oracle's for the same authoring calls: the C++ boundary is a drop-in, not only the Python one."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "cpp", "dropin")
+    assert os.path.exists(exe), "run `make` first"
+    W, H, S = 72, 40, 3
+    out = subprocess.run([exe, str(W), str(H), str(S)], check=True, capture_output=True, text=True).stdout
+    line = [ln for ln in out.splitlines() if ln.startswith("samples")][0].split()
+    assert int(line[1]) == S
+    sc = oracle.OracleScene()
+    sc.add_Material((0, 0, 0), (0, 0, 0), (120, 100, 80), (0, 0, 0), (0, 0, 0), 0, 3)
+    sc.add_Material((0.3, 0.3, 0.3), (0, 0, 0), (0, 0, 0), (0, 0, 0), (0, 0, 0), 50, 0)
+    sc.add_Triangle((300.0, 999.9, 700.0), (300.0, 999.9, 300.0), (700.0, 999.9, 700.0), 0)
+    sc.add_Triangle((700.0, 999.9, 700.0), (300.0, 999.9, 300.0), (700.0, 999.9, 300.0), 0)
+    sc.end_Obj()
+    sc.add_Triangle((-10000.0, 0.0, -10000.0), (-10000.0, 0.0, 10000.0), (10000.0, 0.0, 10000.0), 1)
+    sc.add_Triangle((10000.0, 0.0, 10000.0), (10000.0, 0.0, -10000.0), (-10000.0, 0.0, -10000.0), 1)
+    sc.end_Obj()
+    cam = oracle.make_camera(60, 0, 0, (0, 0, 0), W, H)
+    fr = oracle.OracleFrame(W, H)
+    fr.render(sc, cam, 4, 0, S, nthreads=8)
+    h = 1469598103934665603
+    for u in fr.colors()[:, :3].copy().view(np.uint32).reshape(-1).tolist():
+        h = ((h ^ u) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert line[3] == "%016x" % h
