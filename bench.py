@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--bounces", type=int, default=BOUNCES)
     ap.add_argument("--lds-scene", type=int, default=-1, help="-1 library default, 0/1 force")
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0, help="0 megakernel (default, fastest), 1 wavefront (stream-compacted)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the untimed side measurement of the other variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -108,6 +110,7 @@ def main():
         sc.set_option("lds_scene", args.lds_scene)
     if args.block:
         sc.set_option("block", args.block)
+    sc.set_option("variant", args.variant)
     sc.set_option("timing", 1)
 
     # device memory and stream are torch's: the radiance slab is a torch tensor so that RCCL
@@ -151,10 +154,26 @@ def main():
     out = exchange()
     sync_all()
     dt = time.perf_counter() - t0
+    timed_stats = (sc.stat("segments"), sc.stat("samples"), sc.stat("kernel_ms"), sc.stat("kernel_launches"))
+
+    # ---- side measurement (untimed, not part of `value`): the other formulation, same workload
+    other = None
+    if world == 1 and not args.no_variants:
+        ov = 1 - args.variant
+        sc.set_option("variant", ov)
+        sc.render(args.spp_per_step)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        nside = max(1, min(8, args.steps // 4))
+        for _ in range(nside):
+            sc.render(args.spp_per_step)
+        torch.cuda.synchronize(dev)
+        other = {"variant": "wavefront" if ov == 1 else "megakernel",
+                 "msamples_per_s": W * H * args.spp_per_step * nside / (time.perf_counter() - t1) / 1e6}
+        sc.set_option("variant", args.variant)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    stats = torch.tensor([sc.stat("segments"), sc.stat("samples"), sc.stat("kernel_ms"), sc.stat("kernel_launches")],
-                         dtype=torch.float64, device=dev)
+    stats = torch.tensor(list(timed_stats), dtype=torch.float64, device=dev)
     kmax = stats[2:3].clone()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -171,7 +190,10 @@ def main():
         value = samples / dt / 1e6
         # dominant kernel: k_render.  Algorithmic bytes per launch / mean launch time.
         launches_per_rank = launches / world
-        bytes_per_launch = (BYTES_PER_SAMPLE + BYTES_PER_SEGMENT * dbar) * (samples / launches)
+        if args.variant == 0:
+            bytes_per_launch = (BYTES_PER_SAMPLE + BYTES_PER_SEGMENT * dbar) * (samples / launches)
+        else:   # wf_intersect alone: 32 B ray read + 8 B hit record written per ray of the launch
+            bytes_per_launch = 40.0 * (segs / launches)
         mean_launch_ms = (kms_sum / world) / launches_per_rank
         achieved = bytes_per_launch / (mean_launch_ms * 1e-3) / 1e9
         traffic = None
@@ -191,13 +213,16 @@ def main():
             "config": {"workload": "Cornell box (12 wall/lamp triangles + 2 tessellated spheres = 1,932 triangles), "
                                    "%dx%d, %d bounces, %d spp (%d steps x %d spp)" % (W, H, B, total_spp, args.steps, args.spp_per_step),
                        "parallelism": "tiles%d" % world, "rows_per_block": ROWS_PER_BLOCK,
-                       "kernel": "k_render (fused gen_ray+trace_ray, persistent per pixel)"},
+                       "variant": "megakernel" if args.variant == 0 else "wavefront",
+                       "kernel": "k_render (fused gen_ray+trace_ray, persistent per pixel)" if args.variant == 0 else "wf_intersect (+wf_generate, wf_shade)"},
             "mean_path_segments": dbar, "msegments_per_s": segs / dt / 1e6, "radiance_checksum": checksum,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_render", "mean_launch_ms": mean_launch_ms,
+                         "kernel": "k_render" if args.variant == 0 else "wf_intersect", "mean_launch_ms": mean_launch_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        if other is not None:
+            line["other_variant"] = other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(W, H, B, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -67,6 +67,11 @@ struct pt_context {
     pt_ray* d_rays = nullptr;
     float4* d_ldr = nullptr;
     unsigned long long* d_stats = nullptr;
+    // wavefront variant: path state + queues (allocated on first use)
+    float4* d_wf_state = nullptr;   // 6 x npix float4
+    int32_t* d_wf_queues = nullptr; // 7 x npix int32
+    std::vector<float> cost_boxes;  // 6 floats per complex object (wavefront cost classes)
+    uint32_t* d_wf_counters = nullptr;
     bool own_rnds = true, own_colors = true;
     hipStream_t stream = nullptr;
 
@@ -78,6 +83,9 @@ struct pt_context {
     int lds_scene = 0;   // staging the whole scene in LDS costs occupancy (1 block/CU); measured slower, off by default
     int timing = 0;
     int count_work = 0;
+    int traversal = 0;    // 0 while-while, 1 voting
+    int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
+    int wf_blocks = 2048; // persistent grid of wf_intersect (256 CUs x 8 blocks of 256 threads)
     int min_waves = 4;    // k_render at 128 VGPRs (4 waves/SIMD) measured fastest
     int bvh_policy = 0;   // 0 auto (SAH termination; LDS fit when lds_scene is on), 1 SAH termination, 2 leaves of <= 4, 3 leaves of <= 8
 
@@ -399,6 +407,31 @@ int build_and_pack(pt_context* ctx) {
     ctx->meta.resize(std::max<size_t>(m, 1));
     std::memset(ctx->packets.data(), 0, sizeof(TriPacket) * ctx->packets.size());
     std::memset(ctx->meta.data(), 0, sizeof(TriMeta) * ctx->meta.size());
+    // bounding boxes of the complex objects (more than 16 triangles), for the wavefront cost classes
+    {
+        struct OB { Aabb b; size_t n; };
+        std::vector<OB> obs;
+        for (size_t o = 0; o < ctx->obj_begin.size(); ++o) {
+            const size_t lo = (size_t)ctx->obj_begin[o], hi = o + 1 < ctx->obj_begin.size() ? (size_t)ctx->obj_begin[o + 1] : ctx->tris.size();
+            if (hi - lo <= 16) continue;
+            OB ob;
+            ob.b.reset();
+            ob.n = hi - lo;
+            for (size_t i = lo; i < hi; ++i) ob.b.grow(padded_bounds(ctx->tris[i]));
+            if (std::isfinite(ob.b.half_area())) obs.push_back(ob);
+        }
+        std::sort(obs.begin(), obs.end(), [](const OB& x, const OB& y) { return x.n > y.n; });
+        while (obs.size() > (size_t)kWfMaxCostBoxes) {       // fold the smallest objects into one box
+            obs[obs.size() - 2].b.grow(obs.back().b);
+            obs[obs.size() - 2].n += obs.back().n;
+            obs.pop_back();
+        }
+        ctx->cost_boxes.clear();
+        for (const OB& ob : obs) {
+            for (int a = 0; a < 3; ++a) ctx->cost_boxes.push_back(ob.b.lo[a]);
+            for (int a = 0; a < 3; ++a) ctx->cost_boxes.push_back(ob.b.hi[a]);
+        }
+    }
     for (size_t k = 0; k < m; ++k) {
         const pt_triangle& t = ctx->tris[ctx->orig[k]];
         float* v = ctx->packets[k].v;
@@ -607,10 +640,10 @@ int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int
     if ((e = hipMalloc((void**)&ctx->d_rays, sizeof(pt_ray) * np)) != hipSuccess) return bail("hipMalloc(rays)", e);      // main.cpp:508
     if ((e = hipMalloc((void**)&ctx->d_rnds, sizeof(int32_t) * np)) != hipSuccess) return bail("hipMalloc(rnds)", e);     // main.cpp:509
     if ((e = hipMalloc((void**)&ctx->d_colors, sizeof(float4) * np)) != hipSuccess) return bail("hipMalloc(colors)", e);  // main.cpp:520
-    if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * 8)) != hipSuccess) return bail("hipMalloc(stats)", e);
+    if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * 8 * kStatRows)) != hipSuccess) return bail("hipMalloc(stats)", e);
     if ((e = hipMemset(ctx->d_rays, 0, sizeof(pt_ray) * np)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->d_colors, 0, sizeof(float4) * np)) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8 * kStatRows)) != hipSuccess) return bail("hipMemset", e);
     int rc = pt_seed_default(ctx);                                                                                    // main.cpp:522-527
     if (rc != PT_OK) {
         std::string msg = ctx->err;
@@ -638,6 +671,9 @@ void pt_destroy(pt_context* ctx) {
         if (ctx->d_rays) (void)hipFree(ctx->d_rays);
         if (ctx->d_ldr) (void)hipFree(ctx->d_ldr);
         if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+        if (ctx->d_wf_state) (void)hipFree(ctx->d_wf_state);
+        if (ctx->d_wf_queues) (void)hipFree(ctx->d_wf_queues);
+        if (ctx->d_wf_counters) (void)hipFree(ctx->d_wf_counters);
         if (ctx->own_rnds && ctx->d_rnds) (void)hipFree(ctx->d_rnds);
         if (ctx->own_colors && ctx->d_colors) (void)hipFree(ctx->d_colors);
     }
@@ -743,6 +779,7 @@ static int launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc) 
     lc->lds_bytes = mega_lds_bytes(p, ctx->block);
     lc->count_work = ctx->count_work != 0;
     lc->min_waves = ctx->min_waves;
+    lc->traversal = ctx->traversal;
     ctx->last_lds_bytes = lc->lds_bytes;
     return PT_OK;
 }
@@ -787,6 +824,48 @@ int pt_trace_rays(pt_context* ctx, const pt_camera* cam, int32_t iterations, int
     return time_end(ctx, ep);
 }
 
+static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsamples) {
+    if (rp.iterations > kWfMaxBounces) return fail(ctx, PT_EINVAL, "wavefront variant supports at most 1023 iterations");
+    const size_t np = (size_t)std::max<int64_t>(ctx->npix, 1);
+    if (!ctx->d_wf_state) {
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_state, sizeof(float4) * 6 * np));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_queues, sizeof(int32_t) * 7 * np));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_counters, sizeof(uint32_t) * kWfCounterStride * (kWfMaxBounces + 4)));
+    }
+    WfParams w;
+    w.rp = rp;
+    w.sA = ctx->d_wf_state + 0 * np; w.sB = ctx->d_wf_state + 1 * np; w.sC = ctx->d_wf_state + 2 * np;
+    w.sD = ctx->d_wf_state + 3 * np; w.sE = ctx->d_wf_state + 4 * np; w.sF = ctx->d_wf_state + 5 * np;
+    w.q_ray[0][0] = ctx->d_wf_queues + 0 * np; w.q_ray[0][1] = ctx->d_wf_queues + 1 * np;
+    w.q_ray[1][0] = ctx->d_wf_queues + 2 * np; w.q_ray[1][1] = ctx->d_wf_queues + 3 * np;
+    w.q_cls[0] = ctx->d_wf_queues + 4 * np; w.q_cls[1] = ctx->d_wf_queues + 5 * np; w.q_cls[2] = ctx->d_wf_queues + 6 * np;
+    w.counters = ctx->d_wf_counters;
+    w.npix = (int32_t)ctx->npix;
+    w.n_cbox = ctx->cost_binning ? (int32_t)(ctx->cost_boxes.size() / 6) : 0;
+    for (int b = 0; b < w.n_cbox; ++b)
+        for (int k = 0; k < 6; ++k) w.cbox[b][k] = ctx->cost_boxes[(size_t)b * 6 + k];
+    if (ctx->npix == 0) return PT_OK;
+    const int persistent_blocks = std::max(1, ctx->wf_blocks);
+    for (int32_t k = 0; k < nsamples; ++k) {
+        w.sample = rp.first_sample + k;
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_wf_counters, 0, sizeof(uint32_t) * kWfCounterStride, ctx->stream));
+        PT_HIP(ctx, launch_wf_generate(w, ctx->stream));
+        for (int32_t b = 0; b < rp.iterations; ++b) {
+            EventPair* ep;
+            int rc = time_begin(ctx, &ep);
+            if (rc != PT_OK) return rc;
+            PT_HIP(ctx, launch_wf_intersect(w, b, persistent_blocks, ctx->stream));
+            if ((rc = time_end(ctx, ep)) != PT_OK) return rc;
+            PT_HIP(ctx, launch_wf_shade(w, b, ctx->stream));
+        }
+        if (ctx->timing && ctx->events_used >= 4096) {   // bound the event pool
+            int rc = time_collect(ctx);
+            if (rc != PT_OK) return rc;
+        }
+    }
+    return PT_OK;
+}
+
 int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t nsamples) {
     PT_NEED_DEVICE(ctx);
     int rc = check_ready(ctx, cam);
@@ -799,6 +878,12 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
     p.iterations = iterations;
     p.first_sample = ctx->current_sample;
     p.nsamples = nsamples;
+    if (ctx->variant == 1) {
+        p.lds_scene = 0;
+        if ((rc = render_wavefront(ctx, p, nsamples)) != PT_OK) return rc;
+        ctx->current_sample += nsamples;
+        return PT_OK;
+    }
     decide_lds_scene(ctx, &p);
     LaunchConfig lc;
     launch_cfg(ctx, p, &lc);
@@ -932,6 +1017,13 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         ctx->timing = value ? 1 : 0;
     } else if (k == "count_work") {
         ctx->count_work = value ? 1 : 0;
+    } else if (k == "cost_binning") {
+        ctx->cost_binning = value ? 1 : 0;
+    } else if (k == "traversal") {
+        ctx->traversal = value ? 1 : 0;
+    } else if (k == "wf_blocks") {
+        if (value < 1 || value > 65535) return fail(ctx, PT_EINVAL, "wf_blocks out of range");
+        ctx->wf_blocks = (int)value;
     } else if (k == "min_waves") {
         ctx->min_waves = (int)value;
     } else if (k == "bvh_policy") {
@@ -942,7 +1034,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (ctx->has_device) {
             PT_HIP(ctx, hipSetDevice(ctx->device));
             PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8));
+            PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8 * kStatRows));
         }
         int rc = time_collect(ctx);
         if (rc != PT_OK) return rc;
@@ -970,11 +1062,14 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out) {
         *out = ctx->kernel_ms_acc;
         return PT_OK;
     }
-    if (k == "segments" || k == "samples" || k == "node_visits" || k == "tri_tests") {
-        unsigned long long h[8];
+    if (k == "segments" || k == "samples" || k == "node_visits" || k == "tri_tests" || k == "wave_node_steps" || k == "wave_tri_steps" || k == "heavy16" || k == "heavy32") {
+        std::vector<unsigned long long> rows((size_t)8 * kStatRows);
+        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        PT_HIP(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
-        *out = (double)h[k == "segments" ? 0 : k == "samples" ? 1 : k == "node_visits" ? 2 : 3];
+        PT_HIP(ctx, hipMemcpy(rows.data(), ctx->d_stats, sizeof(unsigned long long) * rows.size(), hipMemcpyDeviceToHost));
+        for (int r = 0; r < kStatRows; ++r)
+            for (int c = 0; c < 8; ++c) h[c] += rows[(size_t)r * 8 + c];
+        *out = (double)h[k == "segments" ? 0 : k == "samples" ? 1 : k == "node_visits" ? 2 : k == "tri_tests" ? 3 : k == "wave_node_steps" ? 4 : k == "wave_tri_steps" ? 5 : k == "heavy16" ? 6 : 7];
         return PT_OK;
     }
     return fail(ctx, PT_EINVAL, "unknown stat: " + k);

@@ -40,6 +40,7 @@ struct TriMeta {
 
 constexpr int kMaxLeaf = 4;        // triangles per leaf (<= 8 by the reference encoding)
 constexpr int kMaxDepth = 30;      // builder guarantees depth <= kMaxDepth
+constexpr int kStatRows = 256;     // statistics counters are spread over this many rows of 8
 constexpr int kStackEntries = 32;  // upper bound of the per-lane traversal stack (far children only)
 
 // ---- kernel parameter block (passed by value, like `Camera` in prog.cl:292-304) ----------
@@ -51,7 +52,7 @@ struct RenderParams {
     int32_t* rnds;          // local pixels
     float4* colors;         // local pixels, float3 @ 16 B
     pt_ray* rays;           // local pixels
-    unsigned long long* stats;   // [0] segments, [1] samples
+    unsigned long long* stats;   // [kStatRows][8]: 0 segments, 1 samples, 2 node visits, 3 tri tests, 4/5 wave-level body runs
     pt_camera cam;
     int32_t width, height;       // GLOBAL frame
     int32_t local_rows;          // rows owned by this context
@@ -62,10 +63,35 @@ struct RenderParams {
     int32_t stack_entries;       // per-lane stack depth actually needed (BVH depth + 1)
 };
 
+// ---- wavefront (stream-compacted) formulation: path state SoA in HBM, indexed by local pixel
+//   sA = {P.xyz, D.x}  sB = {D.y, D.z, t_hit, bits(tri)}  sC = {fL.xyz, fB.x}
+//   sD = {fB.yz, fS.xy}  sE = {fS.z, fR.xyz}  sF = {color.xyz, bits(seed | inside << 31)}
+// = 96 B of state + the 8-B hit record inside sB.  Queues hold local pixel indices.
+// Counter rows (kWfCounterStride words each): row 0 belongs to bounce 0 and is filled by wf_generate
+// (cleared by a memset in front of it); row b+1... see wf_row().  Words: 0 n_ray cheap,
+// 1 n_ray expensive, 2..4 n_class A/B/C.
+constexpr int kWfCounterStride = 8;
+constexpr int kWfMaxBounces = 1023;
+constexpr int kWfGenRow = 0;
+__host__ __device__ inline int wf_row(int bounce) { return bounce == 0 ? kWfGenRow : bounce + 1; }
+constexpr int kWfMaxCostBoxes = 8;
+struct WfParams {
+    RenderParams rp;
+    float4 *sA, *sB, *sC, *sD, *sE, *sF;
+    int32_t* q_ray[2][2];  // [bounce parity][cost class]: intersect input queues
+    int32_t* q_cls[3];     // shade input queues: 0 diffuse/emitter, 1 mirror/dielectric/other, 2 miss
+    uint32_t* counters;    // [(iterations + 2) * kWfCounterStride]
+    float cbox[kWfMaxCostBoxes][6];   // bounding boxes of the complex objects (min xyz, max xyz)
+    int32_t n_cbox;
+    int32_t npix;
+    int32_t sample;        // current_sample of this pass
+};
+
 struct LaunchConfig {
     int block = 256;
     size_t lds_bytes = 0;
     int min_waves = 1;         // __launch_bounds__ second argument (waves per SIMD the allocator must allow)
+    int traversal = 0;         // 0 while-while rounds, 1 wave-voting single steps
     bool count_work = false;   // also count node visits / triangle tests into stats[2], stats[3]
 };
 
@@ -75,6 +101,9 @@ hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipSt
 hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream);
 hipError_t launch_resolve_reinhard(const float4* colors, float4* out, int64_t n, hipStream_t stream);
 hipError_t launch_filt_im(const float4* colors, float4* out, int32_t width, int32_t height, hipStream_t stream);
+hipError_t launch_wf_generate(const WfParams& p, hipStream_t stream);
+hipError_t launch_wf_intersect(const WfParams& p, int bounce, int grid_blocks, hipStream_t stream);
+hipError_t launch_wf_shade(const WfParams& p, int bounce, hipStream_t stream);
 size_t mega_lds_bytes(const RenderParams& p, int block);
 int mega_max_lds_scene_bytes();
 

@@ -21,6 +21,8 @@
 // they are conservative (padded boxes, widened slabs) and only ever cull.
 #include "pt_internal.hpp"
 
+#include <algorithm>
+
 namespace ptamd {
 
 // ---------------------------------------------------------------------------- small math
@@ -233,84 +235,148 @@ struct LaneStack {
 };
 
 struct WorkCount {
-    unsigned nodes, tris;
+    unsigned nodes, tris;     // per-lane visits / tests
+    unsigned wnodes, wtris;   // wave-level executions of the two bodies (counted by the first active lane)
 };
+PT_DEV bool first_active_lane() {
+    const unsigned long long m = __ballot(1);
+    return (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1;
+}
 
-// closest hit over the whole scene; ties in t go to the lower encounter rank (the triangle
-// the reference's traversal, prog.cl:113-184, meets first).  Returns packed triangle index or -1.
-template <class StackT, bool COUNT>
-PT_DEV int closest_hit(const SceneView& sv, f3 P, f3 D, const LaneStack<StackT> stk, float* t_out, WorkCount* wc) {
-    const float kWiden = 1.0000005f;   // > 4 ulp: covers rcp + sub + mul rounding of the slab test
-    const f3 inv = mk(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
-    float best_t = __builtin_inff();
-    int best = -1;
-    int sp = 0;
-    // while-while traversal: every lane first descends through interior nodes until it holds a
-    // leaf (or has finished), then all lanes holding leaves intersect them; repeat.
-    const int kDone = 0x7fffffff;
-    int cur = 0;  // >= 0: interior node index (the root always is one); < 0: leaf reference
-    while (cur != kDone) {
-        while (cur >= 0 && cur != kDone) {
-            const float4 qx = sv.nodes[cur * 4 + 0];
-            const float4 qy = sv.nodes[cur * 4 + 1];
-            const float4 qz = sv.nodes[cur * 4 + 2];
-            const float4 qr = sv.nodes[cur * 4 + 3];
-            if (COUNT) wc->nodes++;
-            const float lx0 = (qx.x - P.x) * inv.x, lx1 = (qx.y - P.x) * inv.x;
-            const float rx0 = (qx.z - P.x) * inv.x, rx1 = (qx.w - P.x) * inv.x;
-            const float ly0 = (qy.x - P.y) * inv.y, ly1 = (qy.y - P.y) * inv.y;
-            const float ry0 = (qy.z - P.y) * inv.y, ry1 = (qy.w - P.y) * inv.y;
-            const float lz0 = (qz.x - P.z) * inv.z, lz1 = (qz.y - P.z) * inv.z;
-            const float rz0 = (qz.z - P.z) * inv.z, rz1 = (qz.w - P.z) * inv.z;
-            const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
-            const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1)) * kWiden;
-            const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
-            const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1)) * kWiden;
-            const float lim = best_t * kWiden;
-            const bool hl = (lf >= ln) && (lf >= 0.0f) && (ln <= lim);
-            const bool hr = (rf >= rn) && (rf >= 0.0f) && (rn <= lim);
-            const int li = __float_as_int(qr.x), ri = __float_as_int(qr.y);
-            if (hl && hr) {
-                const bool lfirst = ln <= rn;
-                cur = lfirst ? li : ri;
-                stk.put(sp, lfirst ? ri : li);
-                ++sp;
-            } else if (hl) {
-                cur = li;
-            } else if (hr) {
-                cur = ri;
-            } else if (sp == 0) {
-                cur = kDone;
-            } else {
-                --sp;
-                cur = stk.get(sp);
-            }
+// Closest hit over the whole scene; ties in t go to the lower encounter rank (the triangle the
+// reference's traversal, prog.cl:113-184, meets first).
+// While-while traversal, one "round" at a time: every lane first descends through interior nodes
+// until it holds a leaf (or has finished), then all lanes holding leaves intersect them.  The
+// per-lane state survives between rounds so that a persistent kernel can hand a finished lane
+// its next ray while the others keep going.
+struct Trav {
+    f3 P, D, inv;
+    float best_t;
+    int best;   // packed triangle index of the closest hit so far, -1 none
+    int sp;
+    int cur;    // >= 0 interior node (the root always is one); < 0 leaf reference; kDone finished
+    int k;      // voting schedule: next triangle of the current leaf
+    static constexpr int kDone = 0x7fffffff;
+
+    PT_DEV void begin(f3 P_, f3 D_) {
+        P = P_;
+        D = D_;
+        inv = mk(__builtin_amdgcn_rcpf(D_.x), __builtin_amdgcn_rcpf(D_.y), __builtin_amdgcn_rcpf(D_.z));
+        best_t = __builtin_inff();
+        best = -1;
+        sp = 0;
+        cur = 0;
+        k = 0;
+    }
+    PT_DEV bool done() const { return cur == kDone; }
+
+    // one interior-node visit: slab-test both children, descend into the nearer hit one, push the other
+    template <class StackT, bool COUNT>
+    PT_DEV void node_step(const SceneView& sv, const LaneStack<StackT> stk, WorkCount* wc) {
+        const float kWiden = 1.0000005f;   // > 4 ulp: covers rcp + sub + mul rounding of the slab test
+        const float4 qx = sv.nodes[cur * 4 + 0];
+        const float4 qy = sv.nodes[cur * 4 + 1];
+        const float4 qz = sv.nodes[cur * 4 + 2];
+        const float4 qr = sv.nodes[cur * 4 + 3];
+        if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; }
+        const float lx0 = (qx.x - P.x) * inv.x, lx1 = (qx.y - P.x) * inv.x;
+        const float rx0 = (qx.z - P.x) * inv.x, rx1 = (qx.w - P.x) * inv.x;
+        const float ly0 = (qy.x - P.y) * inv.y, ly1 = (qy.y - P.y) * inv.y;
+        const float ry0 = (qy.z - P.y) * inv.y, ry1 = (qy.w - P.y) * inv.y;
+        const float lz0 = (qz.x - P.z) * inv.z, lz1 = (qz.y - P.z) * inv.z;
+        const float rz0 = (qz.z - P.z) * inv.z, rz1 = (qz.w - P.z) * inv.z;
+        const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
+        const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1)) * kWiden;
+        const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
+        const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1)) * kWiden;
+        const float lim = best_t * kWiden;
+        const bool hl = (lf >= ln) && (lf >= 0.0f) && (ln <= lim);
+        const bool hr = (rf >= rn) && (rf >= 0.0f) && (rn <= lim);
+        const int li = __float_as_int(qr.x), ri = __float_as_int(qr.y);
+        if (hl && hr) {
+            const bool lfirst = ln <= rn;
+            cur = lfirst ? li : ri;
+            stk.put(sp, lfirst ? ri : li);
+            ++sp;
+        } else if (hl) {
+            cur = li;
+        } else if (hr) {
+            cur = ri;
+        } else if (sp == 0) {
+            cur = kDone;
+        } else {
+            --sp;
+            cur = stk.get(sp);
         }
+    }
+
+    // exact test of packed triangle ti against the ray, keeping the closest (ties: lower rank)
+    template <bool COUNT>
+    PT_DEV void tri_step(const SceneView& sv, int ti, WorkCount* wc) {
+        const float4 a = sv.tris[ti * 3 + 0], b = sv.tris[ti * 3 + 1], c = sv.tris[ti * 3 + 2];
+        if (COUNT) { wc->tris++; if (first_active_lane()) wc->wtris++; }
+        const float t = tri_test(a, b, c, P, D, best_t * 1.000002f);
+        if (t > 0.0f) {
+            bool better = t < best_t;
+            if (t == best_t && best >= 0) better = sv.meta[ti].rank < sv.meta[best].rank;
+            if (better) { best_t = t; best = ti; }
+        }
+    }
+
+    template <class StackT>
+    PT_DEV void pop(const LaneStack<StackT> stk) {
+        if (sp == 0) {
+            cur = kDone;
+        } else {
+            --sp;
+            cur = stk.get(sp);
+        }
+    }
+
+    template <class StackT, bool COUNT>
+    PT_DEV void round(const SceneView& sv, const LaneStack<StackT> stk, WorkCount* wc) {
+        while (cur >= 0 && cur != kDone) node_step<StackT, COUNT>(sv, stk, wc);
         while (cur < 0) {
             const int v = ~cur;
             const int first = v >> 3, count = (v & 7) + 1;
-            const float limit = best_t * 1.000002f;
-            for (int k = 0; k < count; ++k) {
-                const int ti = first + k;
-                const float4 a = sv.tris[ti * 3 + 0], b = sv.tris[ti * 3 + 1], c = sv.tris[ti * 3 + 2];
-                if (COUNT) wc->tris++;
-                const float t = tri_test(a, b, c, P, D, limit);
-                if (t > 0.0f) {
-                    bool better = t < best_t;
-                    if (t == best_t && best >= 0) better = sv.meta[ti].rank < sv.meta[best].rank;
-                    if (better) { best_t = t; best = ti; }
-                }
-            }
-            if (sp == 0) {
-                cur = kDone;
-            } else {
-                --sp;
-                cur = stk.get(sp);
+            for (int k = 0; k < count; ++k) tri_step<COUNT>(sv, first + k, wc);
+            pop(stk);
+        }
+    }
+
+    // Voting schedule: each step the wave runs ONE body -- a node visit or a single triangle test --
+    // whichever more lanes are waiting for.  Lanes in the minority wait (and accumulate), so neither
+    // body is ever executed for a thin tail of lanes as in the while-while loops.
+    template <class StackT, bool COUNT>
+    PT_DEV void vote_step(const SceneView& sv, const LaneStack<StackT> stk, WorkCount* wc) {
+        const bool want_node = cur >= 0 && cur != kDone;
+        const bool want_tri = cur < 0;
+        const int nn = __popcll(__ballot(want_node)), nt = __popcll(__ballot(want_tri));
+        if (nn >= nt) {
+            if (want_node) node_step<StackT, COUNT>(sv, stk, wc);
+        } else if (want_tri) {
+            const int v = ~cur;
+            const int first = v >> 3, count = (v & 7) + 1;
+            tri_step<COUNT>(sv, first + k, wc);
+            if (++k >= count) {
+                k = 0;
+                pop(stk);
             }
         }
     }
-    *t_out = best_t;
-    return best;
+};
+
+template <class StackT, bool COUNT, bool VOTE>
+PT_DEV int closest_hit(const SceneView& sv, f3 P, f3 D, const LaneStack<StackT> stk, float* t_out, WorkCount* wc) {
+    Trav tr;
+    tr.begin(P, D);
+    if (VOTE) {
+        while (__ballot(!tr.done()) != 0) tr.template vote_step<StackT, COUNT>(sv, stk, wc);
+    } else {
+        while (!tr.done()) tr.template round<StackT, COUNT>(sv, stk, wc);
+    }
+    *t_out = tr.best_t;
+    return tr.best;
 }
 
 // ---------------------------------------------------------------------------- BSDF sampling
@@ -458,6 +524,13 @@ PT_DEV void stage_scene(const RenderParams& p, float4* lds_nodes, float4* lds_tr
     __syncthreads();
 }
 
+// statistics live in kStatRows rows of 8 counters; a block adds to the row picked by its index, so
+// no single address sees more than a few dozen atomics per launch (one address saturates at
+// ~88 atomics/us on MI355X, which cost a 32k-wave launch ~0.4 ms when every wave hit one word)
+PT_DEV void stat_add(const RenderParams& p, int slot, unsigned long long v) {
+    atomicAdd(&p.stats[(size_t)((blockIdx.x + blockIdx.y * 37u) % kStatRows) * 8 + slot], v);
+}
+
 PT_DEV unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
@@ -480,7 +553,7 @@ __global__ void __launch_bounds__(256) k_gen_ray(RenderParams p) {
 
 // The render kernel.  SPLIT = true: trace_ray alone (prog.cl:292-381), the ray comes from the
 // rays buffer and one sample is taken; SPLIT = false: nsamples x (gen_ray + trace_ray).
-template <bool SPLIT, bool LDS_SCENE, int BLOCK, class StackT, bool COUNT, int MINW>
+template <bool SPLIT, bool LDS_SCENE, int BLOCK, class StackT, bool COUNT, int MINW, bool VOTE = false>
 __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
     LaneStack<StackT> stk;
     stk.base = reinterpret_cast<StackT*>(pt_lds_raw) + threadIdx.x;          // [entry][lane]
@@ -488,6 +561,8 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
     WorkCount wc;
     wc.nodes = 0;
     wc.tris = 0;
+    wc.wnodes = 0;
+    wc.wtris = 0;
     SceneView sv;
     sv.nodes = p.nodes;
     sv.tris = p.tris;
@@ -501,6 +576,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
     }
     const PixelId px = pixel_of_thread(p);
     unsigned long long segs = 0, samples = 0;
+    unsigned heavy16 = 0, heavy32 = 0, heavy32_nodes = 0;
     if (px.li >= 0) {
         f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
         f3 fL = mk(1.f, 1.f, 1.f), fB = fL, fS = fL, fR = fL, color = mk(0.f, 0.f, 0.f);
@@ -539,7 +615,13 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
             bool finished = true;
             if (bounce < p.iterations) {
                 float t;
-                const int ti = closest_hit<StackT, COUNT>(sv, rP, rD, stk, &t, &wc);
+                const unsigned nodes_before = wc.nodes;
+                const int ti = closest_hit<StackT, COUNT, VOTE>(sv, rP, rD, stk, &t, &wc);
+                if (COUNT) {
+                    const unsigned dn = wc.nodes - nodes_before;
+                    if (dn > 16) { heavy16++; }
+                    if (dn > 32) { heavy32++; heavy32_nodes += dn; }
+                }
                 ++segs;
                 if (ti >= 0) {
                     shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, ti, t);
@@ -566,15 +648,276 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
     samples = wave_sum(samples);
     if (COUNT) {
         const unsigned long long wn = wave_sum((unsigned long long)wc.nodes), wt = wave_sum((unsigned long long)wc.tris);
+        const unsigned long long wwn = wave_sum((unsigned long long)wc.wnodes), wwt = wave_sum((unsigned long long)wc.wtris);
         if ((threadIdx.x & 63) == 0 && p.stats) {
-            atomicAdd(&p.stats[2], wn);
-            atomicAdd(&p.stats[3], wt);
+            stat_add(p, 2, wn);
+            stat_add(p, 3, wt);
+            stat_add(p, 4, wwn);
+            stat_add(p, 5, wwt);
+        }
+        const unsigned long long h16 = wave_sum((unsigned long long)heavy16), h32 = wave_sum(((unsigned long long)heavy32_nodes << 24) | heavy32);
+        if ((threadIdx.x & 63) == 0 && p.stats) {
+            stat_add(p, 6, h16);
+            stat_add(p, 7, h32);
         }
     }
     if ((threadIdx.x & 63) == 0 && p.stats) {
-        atomicAdd(&p.stats[0], segs);
-        atomicAdd(&p.stats[1], samples);
+        stat_add(p, 0, segs);
+        stat_add(p, 1, samples);
     }
+}
+
+// ============================================================================ wavefront
+// Stream-compacted formulation of the same path (BASELINE north_star): one pass = one sample of
+// every local pixel.  generate -> for each bounce { intersect ; shade } with the path state SoA in
+// HBM (WfParams) and index queues between the stages.
+//   wf_generate : 2 LCG draws + camera ray per pixel (prog.cl:384-389), state init (prog.cl:307-316)
+//   wf_intersect: each wave owns 256 consecutive entries of a ray queue and refills a lane as soon
+//                 as its traversal ends (__ballot/__popcll rank inside the wave's range), so no
+//                 lane idles while its neighbours finish long traversals.  At the end the block
+//                 compacts its rays into three class queues by the material type they hit
+//                 (order-preserving ballot scan through LDS, 3 global atomics per 1,024 rays).
+//   wf_shade    : one block row per class -> waves are material-coherent.  Survivors go to the
+//                 next bounce's ray queues; paths that end (miss / last bounce) fold their colour
+//                 into the running mean (prog.cl:379) and store the LCG state.
+// Ray queues come in two COST classes: a ray that misses the bounding boxes of every complex
+// object (more than 16 triangles) can only hit the few large triangles around them and finishes
+// in a handful of steps; mixing it into a wave with rays that walk a 1,000-triangle object leaves
+// its lane idle for most of the wave's life (measured: 16 % lane utilisation in the node loop).
+PT_DEV unsigned long long lanemask_lt() {
+    const unsigned lane = threadIdx.x & 63;
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// Order-preserving append of `value` of every thread with cls in [0, NCLS) to queues[cls];
+// counts at counters[cls].  Every thread of the block must call it.  scratch: NCLS*(WAVES+1) words.
+template <int NCLS, int BLOCK>
+PT_DEV void block_append(int cls, int value, int32_t* const* queues, unsigned* counters, unsigned* scratch) {
+    constexpr int WAVES = BLOCK / 64;
+    const unsigned wave = threadIdx.x >> 6;
+    const unsigned long long lt = lanemask_lt();
+    unsigned myoff = 0;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if ((threadIdx.x & 63) == 0) scratch[c * (WAVES + 1) + wave] = (unsigned)__popcll(m);
+        if (cls == c) myoff = (unsigned)__popcll(m & lt);
+    }
+    __syncthreads();
+    if (threadIdx.x < NCLS) {
+        unsigned* row = scratch + threadIdx.x * (WAVES + 1);
+        unsigned tot = 0;
+        for (int k = 0; k < WAVES; ++k) { const unsigned v = row[k]; row[k] = tot; tot += v; }
+        row[WAVES] = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0u;
+    }
+    __syncthreads();
+    if (cls >= 0 && cls < NCLS) {
+        const unsigned* row = scratch + cls * (WAVES + 1);
+        queues[cls][row[WAVES] + row[wave] + myoff] = value;
+    }
+    __syncthreads();
+}
+
+// 1 = the ray touches the box of a complex object (expensive traversal ahead), 0 = it cannot
+PT_DEV int ray_cost_class(const WfParams& w, f3 P, f3 D) {
+    const f3 inv = mk(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
+    int cost = 0;
+    for (int b = 0; b < w.n_cbox; ++b) {
+        const float x0 = (w.cbox[b][0] - P.x) * inv.x, x1 = (w.cbox[b][3] - P.x) * inv.x;
+        const float y0 = (w.cbox[b][1] - P.y) * inv.y, y1 = (w.cbox[b][4] - P.y) * inv.y;
+        const float z0 = (w.cbox[b][2] - P.z) * inv.z, z1 = (w.cbox[b][5] - P.z) * inv.z;
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * 1.0000005f;
+        if (tf >= tn && tf >= 0.0f) cost = 1;
+    }
+    return cost;
+}
+
+PT_DEV void wf_finalize(const WfParams& w, int li, f3 color, int seed) {
+    f3 acc = mk(0.0f, 0.0f, 0.0f);
+    if (w.sample != 0) {
+        const float4 c = w.rp.colors[li];
+        acc = mk(c.x, c.y, c.z);
+    }
+    acc = running_mean(acc, color, w.sample);
+    w.rp.colors[li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    w.rp.rnds[li] = seed;
+}
+
+__global__ void __launch_bounds__(256) wf_generate(WfParams w) {
+    __shared__ unsigned s_scratch[2 * 5];
+    const int li = blockIdx.x * 256 + threadIdx.x;
+    const RenderParams& p = w.rp;
+    // rows >= 1 (bounces >= 1) are cleared here; row 0 (bounce 0, filled by THIS launch) is cleared by
+    // a memset the host enqueues in front of the kernel
+    if (li >= kWfCounterStride && li < (p.iterations + 3) * kWfCounterStride) w.counters[li] = 0u;
+    int cost = -1;
+    if (li < w.npix) {
+        const int lrow = li / p.width, x = li - lrow * p.width;
+        const int grow = ((lrow / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (lrow % p.rows_per_block);
+        const int gid = grow * p.width + x;
+        int seed = p.rnds[li];
+        const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+        f3 P, D;
+        camera_get_ray(gid, p.cam, rnd1, rnd2, &P, &D);
+        if (p.iterations <= 0) {
+            wf_finalize(w, li, mk(0.0f, 0.0f, 0.0f), seed);
+        } else {
+            w.sA[li] = make_float4(P.x, P.y, P.z, D.x);
+            w.sB[li] = make_float4(D.y, D.z, 0.0f, __int_as_float(-1));
+            w.sC[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            w.sD[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            w.sE[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            w.sF[li] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(seed));
+            cost = ray_cost_class(w, P, D);
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && li < w.npix && p.stats) stat_add(p, 1, (unsigned long long)min(64, w.npix - li));
+    int32_t* queues[2] = {w.q_ray[0][0], w.q_ray[0][1]};
+    block_append<2, 256>(cost, li, queues, w.counters + kWfGenRow * kWfCounterStride, s_scratch);
+}
+
+// Rays per wave: each wave owns a contiguous range of the bounce's ray queue and refills its
+// lanes from it (no global atomics on the fetch side; blocks that finish early are replaced by
+// the dispatcher, which balances the load between CUs).
+constexpr int kWfRaysPerWave = 256;
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
+    constexpr int WAVES = BLOCK / 64;
+    constexpr int RPB = WAVES * kWfRaysPerWave;          // rays per block
+    constexpr int CHUNKS = RPB / 64;
+    const RenderParams& p = w.rp;
+    const int cost = blockIdx.y;
+    unsigned* ctr = w.counters + wf_row(bounce) * kWfCounterStride;
+    const unsigned n = ctr[cost];
+    const unsigned block_base = blockIdx.x * RPB;
+    if (block_base >= n) return;                          // uniform for the whole block
+    // dynamic LDS: [traversal stacks][class byte per ray of the block][CHUNKS x 3 counts][3 bases]
+    LaneStack<unsigned> stk;
+    stk.base = reinterpret_cast<unsigned*>(pt_lds_raw) + threadIdx.x;
+    stk.stride = BLOCK;
+    unsigned char* lds_cls = pt_lds_raw + (size_t)p.stack_entries * 4 * BLOCK;
+    unsigned* lds_cnt = reinterpret_cast<unsigned*>(lds_cls + RPB);     // [CHUNKS][3]
+    unsigned* lds_base = lds_cnt + CHUNKS * 3;                          // [3]
+    SceneView sv;
+    sv.nodes = p.nodes;
+    sv.tris = p.tris;
+    sv.meta = p.meta;
+    const int32_t* __restrict__ q = w.q_ray[bounce & 1][cost];
+    const unsigned long long lt = lanemask_lt();
+    const unsigned wave = threadIdx.x >> 6;
+    unsigned cbase = block_base + wave * kWfRaysPerWave;  // uniform per wave: next unassigned ray
+    const unsigned cend = min(cbase + (unsigned)kWfRaysPerWave, n);
+    if (cbase > cend) cbase = cend;
+    Trav tr;
+    tr.begin(mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f));
+    tr.cur = Trav::kDone;
+    int idx = -1;        // local pixel index of the ray in flight
+    unsigned slot = 0;   // its position inside the block's range
+    WorkCount wc;
+    for (;;) {
+        const unsigned long long idle = __ballot(tr.done());
+        if (idle != 0 && cbase < cend) {                  // refill idle lanes from the wave's range
+            const unsigned my = cbase + (unsigned)__popcll(idle & lt);
+            if (tr.done() && my < cend) {
+                idx = q[my];
+                slot = my - block_base;
+                const float4 a = w.sA[idx];
+                const float4 b = w.sB[idx];
+                tr.begin(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y));
+            }
+            cbase = min(cbase + (unsigned)__popcll(idle), cend);
+        }
+        if (__ballot(!tr.done()) == 0) break;
+        tr.template round<unsigned, false>(sv, stk, &wc);
+        if (tr.done() && idx >= 0) {
+            float2* hitrec = reinterpret_cast<float2*>(&w.sB[idx]) + 1;
+            *hitrec = make_float2(tr.best_t, __int_as_float(tr.best));
+            int cls = 2;
+            if (tr.best >= 0) {
+                const int type = p.mats[sv.meta[tr.best].mati].type;
+                cls = (type == 0 || type == 3) ? 0 : 1;
+            }
+            lds_cls[slot] = (unsigned char)cls;
+            idx = -1;
+        }
+    }
+    // ---- order-preserving compaction of the block's rays into the three class queues
+    __syncthreads();
+    const unsigned nblock = min((unsigned)RPB, n - block_base);
+    unsigned off[RPB / BLOCK];
+    int cl[RPB / BLOCK];
+#pragma unroll
+    for (int k = 0; k < RPB / BLOCK; ++k) {
+        const unsigned r = k * BLOCK + threadIdx.x;
+        cl[k] = r < nblock ? (int)lds_cls[r] : -1;
+        off[k] = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned long long m = __ballot(cl[k] == c);
+            if ((threadIdx.x & 63) == 0) lds_cnt[(r >> 6) * 3 + c] = (unsigned)__popcll(m);
+            if (cl[k] == c) off[k] = (unsigned)__popcll(m & lt);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned tot = 0;
+        for (int ch = 0; ch < CHUNKS; ++ch) { const unsigned v = lds_cnt[ch * 3 + threadIdx.x]; lds_cnt[ch * 3 + threadIdx.x] = tot; tot += v; }
+        lds_base[threadIdx.x] = tot ? atomicAdd(&ctr[2 + threadIdx.x], tot) : 0u;
+    }
+    if (threadIdx.x == 0 && p.stats) stat_add(p, 0, (unsigned long long)nblock);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RPB / BLOCK; ++k) {
+        const unsigned r = k * BLOCK + threadIdx.x;
+        if (cl[k] >= 0) w.q_cls[cl[k]][lds_base[cl[k]] + lds_cnt[(r >> 6) * 3 + cl[k]] + off[k]] = q[block_base + r];
+    }
+}
+
+constexpr int kWfShadeBlock = 1024;
+
+__global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce) {
+    __shared__ unsigned s_scratch[2 * (kWfShadeBlock / 64 + 1)];
+    const RenderParams& p = w.rp;
+    const int cls = blockIdx.y;
+    unsigned* ctr = w.counters + wf_row(bounce) * kWfCounterStride;
+    const unsigned n = ctr[2 + cls];
+    if (blockIdx.x * kWfShadeBlock >= n) return;          // whole block idle
+    const unsigned i = blockIdx.x * kWfShadeBlock + threadIdx.x;
+    int li = 0;
+    int cost = -1;                                        // >= 0: the path continues with a ray of that cost class
+    if (i < n) {
+        li = w.q_cls[cls][i];
+        const float4 F = w.sF[li];
+        f3 color = mk(F.x, F.y, F.z);
+        const int sbits = __float_as_int(F.w);
+        int seed = sbits & 0x7fffffff;
+        bool inside = sbits < 0;
+        if (cls == 2) {                                   // miss: black environment, prog.cl:367-376
+            wf_finalize(w, li, color, seed);
+        } else {
+            const float4 A = w.sA[li], B = w.sB[li], C = w.sC[li], Dq = w.sD[li], E = w.sE[li];
+            f3 rP = mk(A.x, A.y, A.z), rD = mk(A.w, B.x, B.y);
+            f3 fL = mk(C.x, C.y, C.z), fB = mk(C.w, Dq.x, Dq.y), fS = mk(Dq.z, Dq.w, E.x), fR = mk(E.y, E.z, E.w);
+            const float t = B.z;
+            const int ti = __float_as_int(B.w);
+            shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, p.tris, p.meta, ti, t);
+            if (bounce + 1 >= p.iterations) {
+                wf_finalize(w, li, color, seed);
+            } else {
+                w.sA[li] = make_float4(rP.x, rP.y, rP.z, rD.x);
+                w.sB[li] = make_float4(rD.y, rD.z, 0.0f, __int_as_float(-1));
+                w.sC[li] = make_float4(fL.x, fL.y, fL.z, fB.x);
+                w.sD[li] = make_float4(fB.y, fB.z, fS.x, fS.y);
+                w.sE[li] = make_float4(fS.z, fR.x, fR.y, fR.z);
+                w.sF[li] = make_float4(color.x, color.y, color.z, __int_as_float(seed | (inside ? (int)0x80000000 : 0)));
+                cost = ray_cost_class(w, rP, rD);
+            }
+        }
+    }
+    int32_t* queues[2] = {w.q_ray[(bounce + 1) & 1][0], w.q_ray[(bounce + 1) & 1][1]};
+    block_append<2, kWfShadeBlock>(cost, li, queues, w.counters + wf_row(bounce + 1) * kWfCounterStride, s_scratch);
 }
 
 // ---- tone mapping, prog.cl:247-269 (value of write_imagef at prog.cl:380)
@@ -694,6 +1037,11 @@ static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc,
         case 1024: PT_LAUNCH(true, 1024, unsigned);
         }
     } else {
+        if (!SPLIT && lc.block == 256 && lc.traversal == 1) {               // voting schedule
+            auto kern = k_render<SPLIT, false, 256, unsigned, COUNT, 4, true>;
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, p);
+            return hipGetLastError();
+        }
         if (!SPLIT && !COUNT && lc.block == 256 && lc.min_waves > 1) {      // occupancy experiments
             switch (lc.min_waves) {
             case 4: PT_LAUNCH_W(false, 256, unsigned, 4);
@@ -718,6 +1066,24 @@ static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc,
 hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) { return launch_render_t<true, false>(p, lc, stream); }
 hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
     return lc.count_work ? launch_render_t<false, true>(p, lc, stream) : launch_render_t<false, false>(p, lc, stream);
+}
+
+hipError_t launch_wf_generate(const WfParams& w, hipStream_t stream) {
+    const int need = std::max(w.npix, (w.rp.iterations + 3) * kWfCounterStride);
+    hipLaunchKernelGGL(wf_generate, dim3((need + 255) / 256), dim3(256), 0, stream, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_wf_intersect(const WfParams& w, int bounce, int, hipStream_t stream) {
+    constexpr int BLOCK = 256, RPB = (BLOCK / 64) * kWfRaysPerWave;
+    const size_t lds = (size_t)w.rp.stack_entries * 4 * BLOCK + RPB + (RPB / 64) * 3 * 4 + 32;
+    hipLaunchKernelGGL(wf_intersect<BLOCK>, dim3((w.npix + RPB - 1) / RPB, 2), dim3(BLOCK), lds, stream, w, bounce);
+    return hipGetLastError();
+}
+
+hipError_t launch_wf_shade(const WfParams& w, int bounce, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_shade, dim3((w.npix + kWfShadeBlock - 1) / kWfShadeBlock, 3), dim3(kWfShadeBlock), 0, stream, w, bounce);
+    return hipGetLastError();
 }
 
 hipError_t launch_resolve_reinhard(const float4* colors, float4* out, int64_t n, hipStream_t stream) {

@@ -271,3 +271,38 @@ def test_cpp_dropin_host_program(oracle):
     for u in fr.colors()[:, :3].copy().view(np.uint32).reshape(-1).tolist():
         h = ((h ^ u) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert line[3] == "%016x" % h
+
+
+@pytest.mark.parametrize("W,H,bounces,spp", [(96, 72, 8, 4), (50, 37, 5, 3), (1, 1, 4, 5), (130, 9, 1, 2), (33, 65, 0, 2), (256, 256, 4, 16)])
+def test_wavefront_variant(api, oracle, cb_spec, cb_oracle_scene, W, H, bounces, spp):
+    """variant 1: stream-compacted wavefront pipeline (generate -> {persistent intersect with lane
+    refill -> class-sorted shade} per bounce, path state SoA in HBM).  Same bar: bit-identical."""
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.set_option("variant", 1)
+    sc.iterations = bounces
+    sc.render(spp - 1)
+    sc.render(1)
+    fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, bounces, spp)
+    check(sc, fr, "wavefront %dx%d b%d" % (W, H, bounces))
+    assert sc.stat("segments") == segs and sc.stat("samples") == W * H * spp
+
+
+def test_wavefront_tiled_and_mesh(api, oracle, cb_spec, cb_oracle_scene):
+    W, H = 64, 52
+    fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 4, 3)
+    for r in range(3):
+        sc = api.Scene(W, H, rank=r, world=3, rows_per_block=8).load(cb_spec)
+        sc.set_option("variant", 1)
+        sc.iterations = 4
+        sc.render(3)
+        ids = sc.local_pixel_ids()
+        assert same_bits(sc.read_colors()[:, :3], fr.colors()[ids, :3]) and np.array_equal(sc.read_rnds(), fr.rnds()[ids])
+    from opencl_path_tracer_amd import scenes
+    spec = scenes.displaced_grid_mesh(6000)
+    osc = oracle.load_scene(spec)
+    sc = api.Scene(64, 64).load(spec)
+    sc.set_option("variant", 1)
+    sc.iterations = 6
+    sc.render(3)
+    fr2, _ = oracle_render(oracle, osc, spec, 64, 64, 6, 3)
+    check(sc, fr2, "wavefront mesh")

@@ -28,17 +28,18 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
     segs, samples, kms = sc.stat("segments"), sc.stat("samples"), sc.stat("kernel_ms")
     extra = ""
     if count:
-        extra = "  nodes/seg=%.2f tris/seg=%.2f" % (sc.stat("node_visits") / segs, sc.stat("tri_tests") / segs)
+        nv, tt, wn, wt = sc.stat("node_visits"), sc.stat("tri_tests"), sc.stat("wave_node_steps"), sc.stat("wave_tri_steps")
+        wsegs = segs / 64.0
+        h16, h32p = sc.stat("heavy16"), int(sc.stat("heavy32"))
+        h32, h32n = h32p & 0xFFFFFF, h32p >> 24
+        print("   segments with >16 node visits: %.1f%%; >32: %.2f%% (packed counters wrap; indicative only) mean nodes of >32: %.1f" % (100 * h16 / segs, 100.0 * h32 / max(segs, 1), h32n / max(h32, 1)))
+        extra = "  nodes/seg=%.2f tris/seg=%.2f | per wave-segment: node body x%.1f (util %.0f%%), tri body x%.1f (util %.0f%%)" % (
+            nv / segs, tt / segs, wn / wsegs, 100 * nv / (64 * wn), wt / wsegs, 100 * tt / (64 * wt))
     print("%dx%d b%d spp%d %-45s nodes=%d lds_bytes=%6d: %8.1f Msamples/s (kernel %8.1f)  dbar=%.3f  Mseg/s=%.1f%s" % (
         W, H, bounces, spp, str(opts), sc.stat("bvh_nodes"), sc.stat("lds_bytes"), samples / dt / 1e6, samples / kms / 1e3, segs / samples, segs / kms / 1e3, extra), flush=True)
 
 
 if __name__ == "__main__":
     spec = scenes.cornell_box()
-    W, H = 1920, 1080
-    run(W, H, 8, 16, spec, count=True, bvh_policy=1)
-    for mw in (1, 4, 5):
-        run(W, H, 8, 16, spec, min_waves=mw, bvh_policy=1)
-    run(W, H, 8, 16, spec, min_waves=4, bvh_policy=2)
-    run(W, H, 8, 16, spec, block=64, bvh_policy=1)
-    run(W, H, 8, 16, spec, lds_scene=1, block=1024, bvh_policy=2)
+    W, H = 512, 512
+    run(W, H, 8, 2, spec, count=True, reps=1)
