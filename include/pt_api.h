@@ -66,6 +66,8 @@ void pt_material_init(pt_material* m, const float kd[3], const float ks[3], cons
                       const float N[3], const float K[3], float shininess, int32_t type);
 /* Triangle(r1,r2,r3,mati): main.cpp:144-166 (precomputes the unit geometric normal) */
 void pt_triangle_init(pt_triangle* t, const float r1[3], const float r2[3], const float r3[3], uint16_t mati);
+/* n x Triangle(...): verts holds 9 floats per triangle (r1, r2, r3), mati one index each */
+void pt_triangles_init(pt_triangle* out, const float* verts, const uint16_t* mati, int64_t n);
 /* Camera(): main.cpp:311-347, with the globals it reads (global_fov/yaw/pitch/shift,
  * screen_width/height: main.cpp:20-21,30-39) passed as arguments */
 void pt_camera_init(pt_camera* c, float fov, float yaw, float pitch, const float shift[3],
@@ -146,6 +148,10 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out);
  * {rank, mati} pairs, and the add-order index of every packed triangle. */
 int pt_debug_bvh_sizes(const pt_context* ctx, int64_t* nnodes, int64_t* ntris);
 int pt_debug_bvh_copy(const pt_context* ctx, float* nodes, float* tris, int32_t* meta, int32_t* orig);
+/* The authored scene (what the reference keeps in Scene::tris / Scene::mats, main.cpp:366-371):
+ * triangles in add order, materials, and the first triangle of every object. */
+int pt_debug_scene_sizes(const pt_context* ctx, int64_t* ntris, int64_t* nmats, int64_t* nobjs);
+int pt_debug_scene_copy(const pt_context* ctx, pt_triangle* tris, pt_material* mats, int32_t* obj_begin);
 /* the reference's traversal encounter rank of each triangle, in add order */
 int pt_debug_encounter_rank(const pt_context* ctx, int32_t* out, int64_t n);
 

@@ -35,13 +35,14 @@ assert MATERIAL.itemsize == 80 and RAY.itemsize == 32 and TRIANGLE.itemsize == 8
 
 # every symbol include/pt_api.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "pt_material_init", "pt_triangle_init", "pt_camera_init", "pt_create", "pt_create_tiled", "pt_destroy",
+    "pt_material_init", "pt_triangle_init", "pt_triangles_init", "pt_camera_init", "pt_create", "pt_create_tiled", "pt_destroy",
     "pt_last_error", "pt_device_info", "pt_add_material", "pt_add_triangle", "pt_add_triangles", "pt_end_obj",
     "pt_add_obj", "pt_upload_triangles", "pt_upload_materials", "pt_seed_default", "pt_upload_seeds",
     "pt_generate_rays", "pt_trace_rays", "pt_render", "pt_set_current_sample", "pt_get_current_sample", "pt_sync",
     "pt_local_pixel_count", "pt_local_pixel_ids", "pt_read_colors", "pt_read_rnds", "pt_read_rays",
     "pt_resolve_ldr", "pt_bind_framebuffer", "pt_device_colors", "pt_device_rnds", "pt_set_stream",
     "pt_set_option", "pt_get_stat", "pt_debug_bvh_sizes", "pt_debug_bvh_copy", "pt_debug_encounter_rank",
+    "pt_debug_scene_sizes", "pt_debug_scene_copy",
 ]
 
 
@@ -66,6 +67,7 @@ def _load():
 
     sig("pt_material_init", None, vp, fp, fp, fp, fp, fp, f32, i32)
     sig("pt_triangle_init", None, vp, fp, fp, fp, C.c_uint16)
+    sig("pt_triangles_init", None, vp, vp, vp, i64)
     sig("pt_camera_init", None, vp, f32, f32, f32, fp, i32, i32)
     sig("pt_create", C.c_int, C.c_int, i32, i32, C.POINTER(vp))
     sig("pt_create_tiled", C.c_int, C.c_int, i32, i32, i32, i32, i32, C.POINTER(vp))
@@ -102,6 +104,8 @@ def _load():
     sig("pt_debug_bvh_sizes", C.c_int, vp, C.POINTER(i64), C.POINTER(i64))
     sig("pt_debug_bvh_copy", C.c_int, vp, vp, vp, vp, vp)
     sig("pt_debug_encounter_rank", C.c_int, vp, vp, i64)
+    sig("pt_debug_scene_sizes", C.c_int, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64))
+    sig("pt_debug_scene_copy", C.c_int, vp, vp, vp, vp)
     return L
 
 
@@ -139,12 +143,10 @@ def Camera(fov, yaw, pitch, shift, width, height):
 
 def triangles_from_vertices(verts, mati):
     """(n,3,3) float32 vertices + (n,) material indices -> (n,) TRIANGLE records."""
-    verts = np.ascontiguousarray(verts, dtype=np.float32)
+    verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+    mati = np.ascontiguousarray(mati, dtype=np.uint16)
     out = np.zeros(verts.shape[0], dtype=TRIANGLE)
-    fp = C.POINTER(C.c_float)
-    for i in range(verts.shape[0]):
-        LIB.pt_triangle_init(out[i:i + 1].ctypes.data_as(C.c_void_p), verts[i, 0].ctypes.data_as(fp),
-                             verts[i, 1].ctypes.data_as(fp), verts[i, 2].ctypes.data_as(fp), int(mati[i]))
+    LIB.pt_triangles_init(_ptr(out), _ptr(verts), _ptr(mati), verts.shape[0])
     return out
 
 
@@ -341,6 +343,15 @@ class Scene:
         orig = np.zeros(nt.value, dtype=np.int32)
         self._ck(LIB.pt_debug_bvh_copy(self._h, _ptr(nodes), _ptr(tris), _ptr(meta), _ptr(orig)))
         return nodes, tris, meta, orig
+
+    def debug_scene(self):
+        nt, nm, no = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(LIB.pt_debug_scene_sizes(self._h, C.byref(nt), C.byref(nm), C.byref(no)))
+        tris = np.zeros(nt.value, dtype=TRIANGLE)
+        mats = np.zeros(nm.value, dtype=MATERIAL)
+        objs = np.zeros(no.value, dtype=np.int32)
+        self._ck(LIB.pt_debug_scene_copy(self._h, _ptr(tris), _ptr(mats), _ptr(objs)))
+        return tris, mats, objs
 
     def debug_encounter_rank(self, n):
         out = np.empty(n, dtype=np.int32)

@@ -560,6 +560,10 @@ void pt_triangle_init(pt_triangle* t, const float r1[3], const float r2[3], cons
     for (int i = 0; i < 3; ++i) t->N.s[i] = n[i] / length;
 }
 
+void pt_triangles_init(pt_triangle* out, const float* verts, const uint16_t* mati, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) pt_triangle_init(&out[i], verts + 9 * i, verts + 9 * i + 3, verts + 9 * i + 6, mati[i]);
+}
+
 static void rotate_x_ref(float v[3], float gamma) {  // main.cpp:63-70 (trig in double)
     gamma = gamma / 180.0f * 3.141593f;
     const double c = std::cos((double)gamma), s = std::sin((double)gamma);
@@ -1088,6 +1092,22 @@ int pt_debug_bvh_copy(const pt_context* ctx, float* nodes, float* tris, int32_t*
     if (tris) std::memcpy(tris, ctx->packets.data(), sizeof(TriPacket) * ctx->orig.size());
     if (meta) std::memcpy(meta, ctx->meta.data(), sizeof(TriMeta) * ctx->orig.size());
     if (orig) std::memcpy(orig, ctx->orig.data(), sizeof(int32_t) * ctx->orig.size());
+    return PT_OK;
+}
+
+int pt_debug_scene_sizes(const pt_context* ctx, int64_t* ntris, int64_t* nmats, int64_t* nobjs) {
+    if (!ctx) return PT_EINVAL;
+    if (ntris) *ntris = (int64_t)ctx->tris.size();
+    if (nmats) *nmats = (int64_t)ctx->mats.size();
+    if (nobjs) *nobjs = (int64_t)ctx->obj_begin.size();
+    return PT_OK;
+}
+
+int pt_debug_scene_copy(const pt_context* ctx, pt_triangle* tris, pt_material* mats, int32_t* obj_begin) {
+    if (!ctx) return PT_EINVAL;
+    if (tris && !ctx->tris.empty()) std::memcpy(tris, ctx->tris.data(), sizeof(pt_triangle) * ctx->tris.size());
+    if (mats && !ctx->mats.empty()) std::memcpy(mats, ctx->mats.data(), sizeof(pt_material) * ctx->mats.size());
+    if (obj_begin && !ctx->obj_begin.empty()) std::memcpy(obj_begin, ctx->obj_begin.data(), sizeof(int32_t) * ctx->obj_begin.size());
     return PT_OK;
 }
 

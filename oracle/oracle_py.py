@@ -62,10 +62,12 @@ def lib():
     sig("orc_material_make", None, vp, fp, fp, fp, fp, fp, f32, i32)
     sig("orc_triangle_make", None, vp, fp, fp, fp, i32)
     sig("orc_camera_make", None, vp, f32, f32, f32, fp, i32, i32)
+    sig("orc_obj_vertex", None, fp, fp, fp, fp, f32, f32)
     sig("orc_scene_create", vp)
     sig("orc_scene_destroy", None, vp)
     sig("orc_add_material", i32, vp, vp)
     sig("orc_add_triangle", None, vp, vp)
+    sig("orc_add_triangles", None, vp, vp, vp, i64)
     sig("orc_end_obj", i32, vp)
     sig("orc_scene_counts", i32, vp, ip, ip, ip, ip)
     sig("orc_scene_tris", vp, vp)
@@ -138,6 +140,12 @@ def make_camera(fov, yaw, pitch, shift, width, height):
     return c
 
 
+def obj_vertex(v, pos, scale, pitch, yaw):
+    out = (C.c_float * 3)()
+    lib().orc_obj_vertex(out, _f3(v), _f3(pos), _f3(scale), float(pitch), float(yaw))
+    return np.array(list(out), dtype=np.float32)
+
+
 class OracleScene:
     """Mirror of the reference's Scene authoring calls (main.cpp:529-551)."""
 
@@ -165,14 +173,9 @@ class OracleScene:
 
     def add_triangles(self, verts, mati):
         """verts: (n,3,3) float32, mati: (n,) ints -- one add_Triangle per row."""
-        L = lib()
-        verts = np.ascontiguousarray(verts, dtype=np.float32)
-        t = np.zeros(1, dtype=TRIANGLE)
-        fp = C.POINTER(C.c_float)
-        for i in range(verts.shape[0]):
-            L.orc_triangle_make(_ptr(t), verts[i, 0].ctypes.data_as(fp), verts[i, 1].ctypes.data_as(fp),
-                                verts[i, 2].ctypes.data_as(fp), int(mati[i]))
-            L.orc_add_triangle(self.h, _ptr(t))
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+        mati = np.ascontiguousarray(mati, dtype=np.uint16)
+        lib().orc_add_triangles(self.h, _ptr(verts), _ptr(mati), verts.shape[0])
 
     def end_Obj(self):
         rc = lib().orc_end_obj(self.h)

@@ -253,6 +253,15 @@ void orc_camera_make(orc_camera* c, float fov, float yaw, float pitch, const flo
 }
 
 
+/* Scene::add_Obj's per-vertex transform, main.cpp:598-606: negate x, rotate_x(pitch),
+ * rotate_y(yaw), then v*scale+pos (float multiply then add: x86-64 g++, no fma). */
+void orc_obj_vertex(float out[3], const float v[3], const float pos[3], const float scale[3], float pitch, float yaw) {
+    float t[3] = { -v[0], v[1], v[2] };
+    rot_x(t, pitch);
+    rot_y(t, yaw);
+    for (int i = 0; i < 3; ++i) out[i] = t[i] * scale[i] + pos[i];
+}
+
 /* ------------------------------------------------------------------ Scene + kd tree */
 typedef struct hnode {            /* NodeOnHost, main.cpp:195-209 */
     struct hnode *left, *right;
@@ -312,6 +321,14 @@ void orc_add_triangle(orc_scene* s, const orc_triangle* t) {          /* main.cp
     }
     s->orig[s->ntris] = s->ntris;
     s->tris[s->ntris++] = *t;
+}
+
+void orc_add_triangles(orc_scene* s, const float* v, const uint16_t* mati, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        orc_triangle t;
+        orc_triangle_make(&t, v + 9 * i, v + 9 * i + 3, v + 9 * i + 6, mati[i]);
+        orc_add_triangle(s, &t);
+    }
 }
 
 /* Triangle::bbox / midpoint / BBox::expand, main.cpp:131-136, 167-181 */

@@ -76,11 +76,15 @@ void orc_triangle_make(orc_triangle* t, const float r1[3], const float r2[3], co
 void orc_camera_make(orc_camera* c, float fov, float yaw, float pitch, const float shift[3],
                      int width, int height);                                           /* main.cpp:311-347 */
 
+void orc_obj_vertex(float out[3], const float v[3], const float pos[3], const float scale[3],
+                    float pitch, float yaw);                                         /* main.cpp:598-606 */
+
 /* ---- Scene: main.cpp:529-551, 618-634 */
 orc_scene* orc_scene_create(void);
 void orc_scene_destroy(orc_scene*);
 int  orc_add_material(orc_scene*, const orc_material*);
 void orc_add_triangle(orc_scene*, const orc_triangle*);
+void orc_add_triangles(orc_scene*, const float* verts9, const uint16_t* mati, int64_t n);   /* n x Triangle(...) + add_Triangle */
 int  orc_end_obj(orc_scene*);                 /* 0 ok; <0 = reference would not terminate / overflow */
 int  orc_scene_counts(const orc_scene*, int* ntris, int* nnodes, int* nobj, int* nmats);
 const orc_triangle* orc_scene_tris(const orc_scene*);      /* leaf-ordered, main.cpp:548-549 */

@@ -306,3 +306,43 @@ def test_wavefront_tiled_and_mesh(api, oracle, cb_spec, cb_oracle_scene):
     sc.render(3)
     fr2, _ = oracle_render(oracle, osc, spec, 64, 64, 6, 3)
     check(sc, fr2, "wavefront mesh")
+
+
+@pytest.mark.parametrize("ntris,W,H,bounces,spp,variant", [(100000, 96, 64, 8, 2, 0), (100000, 64, 48, 8, 2, 1), (1000000, 48, 48, 16, 2, 0)])
+def test_mesh_configs_c3_c5(api, oracle, ntris, W, H, bounces, spp, variant):
+    """BASELINE configs 3 and 5 (MESH-100k at 8 bounces, MESH-1M at 16 bounces: SURVEY 8d synthetic
+    displaced-grid meshes inside the Cornell walls) at frame sizes the oracle finishes in seconds."""
+    from opencl_path_tracer_amd import scenes
+    spec = scenes.displaced_grid_mesh(ntris)
+    osc = oracle.load_scene(spec)
+    sc = api.Scene(W, H).load(spec)
+    sc.set_option("variant", variant)
+    sc.iterations = bounces
+    sc.render(spp)
+    fr, segs = oracle_render(oracle, osc, spec, W, H, bounces, spp)
+    check(sc, fr, "mesh %d" % ntris)
+    assert sc.stat("segments") == segs
+
+
+def test_4k_frame_properties_c4(api, cb_spec):
+    """BASELINE config 4 size (3840x2160, 8 bounces): the union of eight ranks' tiles (all rendered on
+    this one GPU) equals the single-context frame; one sample."""
+    W, H, B = 3840, 2160, 8
+    a = api.Scene(W, H).load(cb_spec)
+    a.iterations = B
+    a.render(1)
+    ca, ra = a.read_colors(), a.read_rnds()
+    del a
+    x_r = np.uint32(0)
+    x_c = np.uint32(0)
+    for r in range(8):
+        t = api.Scene(W, H, rank=r, world=8, rows_per_block=8).load(cb_spec)
+        t.iterations = B
+        t.render(1)
+        ids = t.local_pixel_ids()
+        tc, trn = t.read_colors(), t.read_rnds()
+        assert same_bits(tc, ca[ids]) and np.array_equal(trn, ra[ids])
+        x_r ^= np.bitwise_xor.reduce(trn.view(np.uint32))
+        x_c ^= np.bitwise_xor.reduce(tc.view(np.uint32).reshape(-1))
+        del t
+    assert x_r == np.bitwise_xor.reduce(ra.view(np.uint32)) and x_c == np.bitwise_xor.reduce(ca.view(np.uint32).reshape(-1))
