@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0, help="0 megakernel (default, fastest), 1 wavefront (stream-compacted)")
     ap.add_argument("--no-variants", action="store_true", help="skip the untimed side measurement of the other variant")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: all ranks share cuda:0 and the exchange runs over gloo on host copies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -96,15 +98,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gpu_index = 0 if args.rehearse_on_one_gpu else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    comm_dev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H, B = args.width, args.height, args.bounces
     spec = scenes.cornell_box()
-    sc = api.Scene(W, H, device=local_rank, rank=rank, world=world, rows_per_block=ROWS_PER_BLOCK).load(spec)
+    sc = api.Scene(W, H, device=gpu_index, rank=rank, world=world, rows_per_block=ROWS_PER_BLOCK).load(spec)
     sc.iterations = B
     if args.lds_scene >= 0:
         sc.set_option("lds_scene", args.lds_scene)
@@ -124,9 +131,9 @@ def main():
     sc.bind_framebuffer(slab.data_ptr(), rnds.data_ptr())
     stream = torch.cuda.current_stream(dev)
     sc.set_stream(stream.cuda_stream)
-    gathered = torch.empty((world * tmap.max_count, 4), dtype=torch.float32, device=dev) if world > 1 else None
-    frame = torch.empty((W * H + 1, 4), dtype=torch.float32, device=dev) if world > 1 else None
-    scatter_index = tmap.gather_index(dev) if world > 1 else None
+    gathered = torch.empty((world * tmap.max_count, 4), dtype=torch.float32, device=comm_dev) if world > 1 else None
+    frame = torch.empty((W * H + 1, 4), dtype=torch.float32, device=comm_dev) if world > 1 else None
+    scatter_index = tmap.gather_index(comm_dev) if world > 1 else None
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -135,7 +142,8 @@ def main():
         torch.cuda.synchronize(dev)
 
     def exchange():
-        return exchange_frame(slab, tmap, scatter_index, gathered, frame)
+        src = slab.to(comm_dev) if (world > 1 and comm_dev != dev) else slab
+        return exchange_frame(src, tmap, scatter_index, gathered, frame)
 
     # ---- warmup (untimed)
     for _ in range(args.warmup):
@@ -172,8 +180,8 @@ def main():
                  "msamples_per_s": W * H * args.spp_per_step * nside / (time.perf_counter() - t1) / 1e6}
         sc.set_option("variant", args.variant)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    stats = torch.tensor(list(timed_stats), dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+    stats = torch.tensor(list(timed_stats), dtype=torch.float64, device=comm_dev)
     kmax = stats[2:3].clone()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

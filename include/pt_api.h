@@ -148,6 +148,9 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out);
  * {rank, mati} pairs, and the add-order index of every packed triangle. */
 int pt_debug_bvh_sizes(const pt_context* ctx, int64_t* nnodes, int64_t* ntris);
 int pt_debug_bvh_copy(const pt_context* ctx, float* nodes, float* tris, int32_t* meta, int32_t* orig);
+/* Closest hit of n caller-supplied rays through the device traversal (kd_intersect, prog.cl:144-184):
+ * out_t[i] = t (-1 on a miss), out_tri[i] = add-order index of the triangle hit (-1 on a miss). */
+int pt_debug_closest_hit(pt_context* ctx, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri);
 /* The authored scene (what the reference keeps in Scene::tris / Scene::mats, main.cpp:366-371):
  * triangles in add order, materials, and the first triangle of every object. */
 int pt_debug_scene_sizes(const pt_context* ctx, int64_t* ntris, int64_t* nmats, int64_t* nobjs);

@@ -42,7 +42,7 @@ EXPORTS = [
     "pt_local_pixel_count", "pt_local_pixel_ids", "pt_read_colors", "pt_read_rnds", "pt_read_rays",
     "pt_resolve_ldr", "pt_bind_framebuffer", "pt_device_colors", "pt_device_rnds", "pt_set_stream",
     "pt_set_option", "pt_get_stat", "pt_debug_bvh_sizes", "pt_debug_bvh_copy", "pt_debug_encounter_rank",
-    "pt_debug_scene_sizes", "pt_debug_scene_copy",
+    "pt_debug_scene_sizes", "pt_debug_scene_copy", "pt_debug_closest_hit",
 ]
 
 
@@ -106,6 +106,7 @@ def _load():
     sig("pt_debug_encounter_rank", C.c_int, vp, vp, i64)
     sig("pt_debug_scene_sizes", C.c_int, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64))
     sig("pt_debug_scene_copy", C.c_int, vp, vp, vp, vp)
+    sig("pt_debug_closest_hit", C.c_int, vp, vp, i64, vp, vp)
     return L
 
 
@@ -352,6 +353,13 @@ class Scene:
         objs = np.zeros(no.value, dtype=np.int32)
         self._ck(LIB.pt_debug_scene_copy(self._h, _ptr(tris), _ptr(mats), _ptr(objs)))
         return tris, mats, objs
+
+    def debug_closest_hit(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY)
+        t = np.empty(rays.shape[0], dtype=np.float32)
+        tri = np.empty(rays.shape[0], dtype=np.int32)
+        self._ck(LIB.pt_debug_closest_hit(self._h, _ptr(rays), rays.shape[0], _ptr(t), _ptr(tri)))
+        return t, tri
 
     def debug_encounter_rank(self, n):
         out = np.empty(n, dtype=np.int32)

@@ -68,8 +68,8 @@ struct pt_context {
     float4* d_ldr = nullptr;
     unsigned long long* d_stats = nullptr;
     // wavefront variant: path state + queues (allocated on first use)
-    float4* d_wf_state = nullptr;   // 6 x npix float4
-    int32_t* d_wf_queues = nullptr; // 7 x npix int32
+    float4* d_wf_state = nullptr;   // 4 (state) + 8 (ray streams) x npix float4, + 2 x npix float2 (hits)
+    int32_t* d_wf_queues = nullptr; // 3 x npix int32 (class queues)
     std::vector<float> cost_boxes;  // 6 floats per complex object (wavefront cost classes)
     uint32_t* d_wf_counters = nullptr;
     bool own_rnds = true, own_colors = true;
@@ -832,17 +832,22 @@ static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsa
     if (rp.iterations > kWfMaxBounces) return fail(ctx, PT_EINVAL, "wavefront variant supports at most 1023 iterations");
     const size_t np = (size_t)std::max<int64_t>(ctx->npix, 1);
     if (!ctx->d_wf_state) {
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_state, sizeof(float4) * 6 * np));
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_queues, sizeof(int32_t) * 7 * np));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_state, sizeof(float4) * 13 * np));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_queues, sizeof(int32_t) * 3 * np));
         PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_counters, sizeof(uint32_t) * kWfCounterStride * (kWfMaxBounces + 4)));
     }
     WfParams w;
     w.rp = rp;
-    w.sA = ctx->d_wf_state + 0 * np; w.sB = ctx->d_wf_state + 1 * np; w.sC = ctx->d_wf_state + 2 * np;
-    w.sD = ctx->d_wf_state + 3 * np; w.sE = ctx->d_wf_state + 4 * np; w.sF = ctx->d_wf_state + 5 * np;
-    w.q_ray[0][0] = ctx->d_wf_queues + 0 * np; w.q_ray[0][1] = ctx->d_wf_queues + 1 * np;
-    w.q_ray[1][0] = ctx->d_wf_queues + 2 * np; w.q_ray[1][1] = ctx->d_wf_queues + 3 * np;
-    w.q_cls[0] = ctx->d_wf_queues + 4 * np; w.q_cls[1] = ctx->d_wf_queues + 5 * np; w.q_cls[2] = ctx->d_wf_queues + 6 * np;
+    w.sC = ctx->d_wf_state + 0 * np; w.sD = ctx->d_wf_state + 1 * np;
+    w.sE = ctx->d_wf_state + 2 * np; w.sF = ctx->d_wf_state + 3 * np;
+    for (int par = 0; par < 2; ++par)
+        for (int c = 0; c < 2; ++c) {
+            w.rsA[par][c] = ctx->d_wf_state + (size_t)(4 + (par * 2 + c) * 2 + 0) * np;
+            w.rsB[par][c] = ctx->d_wf_state + (size_t)(4 + (par * 2 + c) * 2 + 1) * np;
+        }
+    w.hit[0] = reinterpret_cast<float2*>(ctx->d_wf_state + 12 * np);
+    w.hit[1] = w.hit[0] + np;
+    w.q_cls[0] = ctx->d_wf_queues + 0 * np; w.q_cls[1] = ctx->d_wf_queues + 1 * np; w.q_cls[2] = ctx->d_wf_queues + 2 * np;
     w.counters = ctx->d_wf_counters;
     w.npix = (int32_t)ctx->npix;
     w.n_cbox = ctx->cost_binning ? (int32_t)(ctx->cost_boxes.size() / 6) : 0;
@@ -1024,7 +1029,8 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "cost_binning") {
         ctx->cost_binning = value ? 1 : 0;
     } else if (k == "traversal") {
-        ctx->traversal = value ? 1 : 0;
+        if (value < 0 || value > 64) return fail(ctx, PT_EINVAL, "traversal: 0 while-while, 1 voting, n >= 2 sliced with n-1 rounds per trip");
+        ctx->traversal = (int)value;
     } else if (k == "wf_blocks") {
         if (value < 1 || value > 65535) return fail(ctx, PT_EINVAL, "wf_blocks out of range");
         ctx->wf_blocks = (int)value;
@@ -1092,6 +1098,35 @@ int pt_debug_bvh_copy(const pt_context* ctx, float* nodes, float* tris, int32_t*
     if (tris) std::memcpy(tris, ctx->packets.data(), sizeof(TriPacket) * ctx->orig.size());
     if (meta) std::memcpy(meta, ctx->meta.data(), sizeof(TriMeta) * ctx->orig.size());
     if (orig) std::memcpy(orig, ctx->orig.data(), sizeof(int32_t) * ctx->orig.size());
+    return PT_OK;
+}
+
+int pt_debug_closest_hit(pt_context* ctx, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri) {
+    PT_NEED_DEVICE(ctx);
+    if (!rays || !out_t || !out_tri || n < 0) return fail(ctx, PT_EINVAL, "bad arguments");
+    if (!ctx->tris_uploaded) return fail(ctx, PT_EINVAL, "pt_upload_triangles has not been called");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    pt_camera cam;
+    std::memset(&cam, 0, sizeof cam);
+    RenderParams p;
+    fill_params(ctx, &cam, &p);
+    pt_ray* d_rays = nullptr;
+    float* d_t = nullptr;
+    int32_t* d_tri = nullptr;
+    const size_t nn = (size_t)std::max<int64_t>(n, 1);
+    PT_HIP(ctx, hipMalloc((void**)&d_rays, sizeof(pt_ray) * nn));
+    PT_HIP(ctx, hipMalloc((void**)&d_t, sizeof(float) * nn));
+    PT_HIP(ctx, hipMalloc((void**)&d_tri, sizeof(int32_t) * nn));
+    PT_HIP(ctx, hipMemcpy(d_rays, rays, sizeof(pt_ray) * (size_t)n, hipMemcpyHostToDevice));
+    PT_HIP(ctx, launch_debug_closest_hit(p, d_rays, n, d_t, d_tri, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(out_t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    PT_HIP(ctx, hipMemcpy(out_tri, d_tri, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i)
+        if (out_tri[i] >= 0) out_tri[i] = ctx->orig[(size_t)out_tri[i]];      // packed -> add order
+    (void)hipFree(d_rays);
+    (void)hipFree(d_t);
+    (void)hipFree(d_tri);
     return PT_OK;
 }
 

@@ -63,13 +63,16 @@ struct RenderParams {
     int32_t stack_entries;       // per-lane stack depth actually needed (BVH depth + 1)
 };
 
-// ---- wavefront (stream-compacted) formulation: path state SoA in HBM, indexed by local pixel
-//   sA = {P.xyz, D.x}  sB = {D.y, D.z, t_hit, bits(tri)}  sC = {fL.xyz, fB.x}
-//   sD = {fB.yz, fS.xy}  sE = {fS.z, fR.xyz}  sF = {color.xyz, bits(seed | inside << 31)}
-// = 96 B of state + the 8-B hit record inside sB.  Queues hold local pixel indices.
-// Counter rows (kWfCounterStride words each): row 0 belongs to bounce 0 and is filled by wf_generate
-// (cleared by a memset in front of it); row b+1... see wf_row().  Words: 0 n_ray cheap,
-// 1 n_ray expensive, 2..4 n_class A/B/C.
+// ---- wavefront (stream-compacted) formulation
+// Per local pixel (index li), 64 B:  sC = {fL.xyz, fB.x}  sD = {fB.yz, fS.xy}  sE = {fS.z, fR.xyz}
+//                                    sF = {color.xyz, bits(seed | inside << 31)}
+// Ray streams, one per (bounce parity, cost class), addressed by POSITION (compact, written and
+// read coalesced), 32 B per ray:     rsA = {P.xyz, D.x}  rsB = {D.y, D.z, bits(li), 0}
+// Hit stream, parallel to the ray stream of the current bounce, 8 B:  hit = {t, bits(tri)}
+// Class queues (shade input): entries (cost << 31) | position.
+// Counter rows (kWfCounterStride words each), see wf_row(): 0 n_ray cheap, 1 n_ray expensive,
+// 2..4 n_class A/B/C.  Row 0 belongs to bounce 0 (filled by wf_generate, cleared by a memset in
+// front of it); bounce b >= 1 uses row b + 1 (cleared by wf_generate).
 constexpr int kWfCounterStride = 8;
 constexpr int kWfMaxBounces = 1023;
 constexpr int kWfGenRow = 0;
@@ -77,10 +80,12 @@ __host__ __device__ inline int wf_row(int bounce) { return bounce == 0 ? kWfGenR
 constexpr int kWfMaxCostBoxes = 8;
 struct WfParams {
     RenderParams rp;
-    float4 *sA, *sB, *sC, *sD, *sE, *sF;
-    int32_t* q_ray[2][2];  // [bounce parity][cost class]: intersect input queues
+    float4 *sC, *sD, *sE, *sF;
+    float4* rsA[2][2];     // [bounce parity][cost class]
+    float4* rsB[2][2];
+    float2* hit[2];        // [cost class]
     int32_t* q_cls[3];     // shade input queues: 0 diffuse/emitter, 1 mirror/dielectric/other, 2 miss
-    uint32_t* counters;    // [(iterations + 2) * kWfCounterStride]
+    uint32_t* counters;    // [(iterations + 3) * kWfCounterStride]
     float cbox[kWfMaxCostBoxes][6];   // bounding boxes of the complex objects (min xyz, max xyz)
     int32_t n_cbox;
     int32_t npix;
@@ -104,6 +109,7 @@ hipError_t launch_filt_im(const float4* colors, float4* out, int32_t width, int3
 hipError_t launch_wf_generate(const WfParams& p, hipStream_t stream);
 hipError_t launch_wf_intersect(const WfParams& p, int bounce, int grid_blocks, hipStream_t stream);
 hipError_t launch_wf_shade(const WfParams& p, int bounce, hipStream_t stream);
+hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, hipStream_t stream);
 size_t mega_lds_bytes(const RenderParams& p, int block);
 int mega_max_lds_scene_bytes();
 

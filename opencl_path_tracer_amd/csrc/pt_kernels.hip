@@ -667,6 +667,95 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
     }
 }
 
+// Sliced variant of the render kernel (option traversal = 2).  In k_render a lane whose traversal
+// ends early idles until the slowest ray of the wave is done (measured: the node body runs 57 times
+// per wave and segment while the average lane needs 9.4).  Here a traversal is advanced by at most
+// `slice` rounds per trip of the main loop; lanes that finished shade and start their next segment
+// in the same trip, lanes with long traversals simply carry their Trav state into the next trip.
+template <int BLOCK, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_render_sliced(RenderParams p, int slice) {
+    LaneStack<unsigned> stk;
+    stk.base = reinterpret_cast<unsigned*>(pt_lds_raw) + threadIdx.x;
+    stk.stride = BLOCK;
+    WorkCount wc;
+    SceneView sv;
+    sv.nodes = p.nodes;
+    sv.tris = p.tris;
+    sv.meta = p.meta;
+    const PixelId px = pixel_of_thread(p);
+    unsigned long long segs = 0, samples = 0;
+    if (px.li >= 0) {
+        f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
+        f3 fL = mk(1.f, 1.f, 1.f), fB = fL, fS = fL, fR = fL, color = mk(0.f, 0.f, 0.f);
+        bool inside = false;
+        int seed = p.rnds[px.li];
+        f3 acc = mk(0.0f, 0.0f, 0.0f);
+        if (p.first_sample != 0) {
+            const float4 c = p.colors[px.li];
+            acc = mk(c.x, c.y, c.z);
+        }
+        int s = p.first_sample;
+        const int s_end = p.first_sample + p.nsamples;
+        int bounce = 0;
+        bool fresh = true, traversing = false;
+        Trav tr;
+        tr.begin(rP, rD);
+        tr.cur = Trav::kDone;
+        for (;;) {
+            if (!traversing) {
+                if (fresh) {
+                    if (s == s_end) break;
+                    fL = mk(1.f, 1.f, 1.f);    // prog.cl:307-316
+                    fB = fL;
+                    fS = fL;
+                    fR = fL;
+                    color = mk(0.f, 0.f, 0.f);
+                    inside = false;
+                    const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+                    camera_get_ray(px.gid, p.cam, rnd1, rnd2, &rP, &rD);
+                    bounce = 0;
+                    fresh = false;
+                }
+                traversing = true;
+                if (bounce < p.iterations) {
+                    tr.begin(rP, rD);
+                    ++segs;
+                } else {                        // iterations == 0: nothing to trace
+                    tr.cur = Trav::kDone;
+                    tr.best = -1;
+                }
+            }
+            for (int r = 0; r < slice; ++r) {
+                if (__ballot(!tr.done()) == 0) break;
+                if (!tr.done()) tr.template round<unsigned, false>(sv, stk, &wc);
+            }
+            if (tr.done()) {
+                traversing = false;
+                bool finished = true;
+                if (tr.best >= 0) {
+                    shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, tr.best, tr.best_t);
+                    ++bounce;
+                    finished = (bounce >= p.iterations);
+                }
+                if (finished) {
+                    acc = running_mean(acc, color, s);
+                    ++s;
+                    ++samples;
+                    fresh = true;
+                }
+            }
+        }
+        p.colors[px.li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        p.rnds[px.li] = seed;
+    }
+    segs = wave_sum(segs);
+    samples = wave_sum(samples);
+    if ((threadIdx.x & 63) == 0 && p.stats) {
+        stat_add(p, 0, segs);
+        stat_add(p, 1, samples);
+    }
+}
+
 // ============================================================================ wavefront
 // Stream-compacted formulation of the same path (BASELINE north_star): one pass = one sample of
 // every local pixel.  generate -> for each bounce { intersect ; shade } with the path state SoA in
@@ -689,10 +778,11 @@ PT_DEV unsigned long long lanemask_lt() {
     return lane == 0 ? 0ull : (~0ull >> (64 - lane));
 }
 
-// Order-preserving append of `value` of every thread with cls in [0, NCLS) to queues[cls];
-// counts at counters[cls].  Every thread of the block must call it.  scratch: NCLS*(WAVES+1) words.
+// Order-preserving slot reservation: every thread with cls in [0, NCLS) gets the next free
+// position of stream/queue `cls` (count at counters[cls]); returns it, or ~0u.  Every thread of the
+// block must call it.  scratch: NCLS*(WAVES+1) words.
 template <int NCLS, int BLOCK>
-PT_DEV void block_append(int cls, int value, int32_t* const* queues, unsigned* counters, unsigned* scratch) {
+PT_DEV unsigned block_reserve(int cls, unsigned* counters, unsigned* scratch) {
     constexpr int WAVES = BLOCK / 64;
     const unsigned wave = threadIdx.x >> 6;
     const unsigned long long lt = lanemask_lt();
@@ -711,11 +801,13 @@ PT_DEV void block_append(int cls, int value, int32_t* const* queues, unsigned* c
         row[WAVES] = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0u;
     }
     __syncthreads();
+    unsigned pos = ~0u;
     if (cls >= 0 && cls < NCLS) {
         const unsigned* row = scratch + cls * (WAVES + 1);
-        queues[cls][row[WAVES] + row[wave] + myoff] = value;
+        pos = row[WAVES] + row[wave] + myoff;
     }
     __syncthreads();
+    return pos;
 }
 
 // 1 = the ray touches the box of a complex object (expensive traversal ahead), 0 = it cannot
@@ -752,19 +844,17 @@ __global__ void __launch_bounds__(256) wf_generate(WfParams w) {
     // a memset the host enqueues in front of the kernel
     if (li >= kWfCounterStride && li < (p.iterations + 3) * kWfCounterStride) w.counters[li] = 0u;
     int cost = -1;
+    f3 P = mk(0.f, 0.f, 0.f), D = mk(0.f, 0.f, 1.f);
     if (li < w.npix) {
         const int lrow = li / p.width, x = li - lrow * p.width;
         const int grow = ((lrow / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (lrow % p.rows_per_block);
         const int gid = grow * p.width + x;
         int seed = p.rnds[li];
         const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
-        f3 P, D;
         camera_get_ray(gid, p.cam, rnd1, rnd2, &P, &D);
         if (p.iterations <= 0) {
             wf_finalize(w, li, mk(0.0f, 0.0f, 0.0f), seed);
         } else {
-            w.sA[li] = make_float4(P.x, P.y, P.z, D.x);
-            w.sB[li] = make_float4(D.y, D.z, 0.0f, __int_as_float(-1));
             w.sC[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
             w.sD[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
             w.sE[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
@@ -773,15 +863,21 @@ __global__ void __launch_bounds__(256) wf_generate(WfParams w) {
         }
     }
     if ((threadIdx.x & 63) == 0 && li < w.npix && p.stats) stat_add(p, 1, (unsigned long long)min(64, w.npix - li));
-    int32_t* queues[2] = {w.q_ray[0][0], w.q_ray[0][1]};
-    block_append<2, 256>(cost, li, queues, w.counters + kWfGenRow * kWfCounterStride, s_scratch);
+    const unsigned pos = block_reserve<2, 256>(cost, w.counters + kWfGenRow * kWfCounterStride, s_scratch);
+    if (cost >= 0) {
+        w.rsA[0][cost][pos] = make_float4(P.x, P.y, P.z, D.x);
+        w.rsB[0][cost][pos] = make_float4(D.y, D.z, __int_as_float(li), 0.0f);
+    }
 }
 
-// Rays per wave: each wave owns a contiguous range of the bounce's ray queue and refills its
-// lanes from it (no global atomics on the fetch side; blocks that finish early are replaced by
-// the dispatcher, which balances the load between CUs).
+// Rays per wave: each wave owns a contiguous range of the bounce's ray stream (no global atomics
+// on the fetch side; blocks that finish early are replaced by the dispatcher).
 constexpr int kWfRaysPerWave = 256;
 
+// Flat traversal loop: every iteration each lane performs at most one node visit and then at most
+// one triangle test, and a lane whose ray is finished takes the next ray of the wave's range in the
+// SAME iteration (the next ray's 32 B are prefetched one assignment ahead, so the switch costs no
+// memory round trip).  No lane ever waits for another lane's traversal to end.
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
     constexpr int WAVES = BLOCK / 64;
@@ -804,7 +900,9 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
     sv.nodes = p.nodes;
     sv.tris = p.tris;
     sv.meta = p.meta;
-    const int32_t* __restrict__ q = w.q_ray[bounce & 1][cost];
+    const float4* __restrict__ rsA = w.rsA[bounce & 1][cost];
+    const float4* __restrict__ rsB = w.rsB[bounce & 1][cost];
+    float2* __restrict__ hits = w.hit[cost];
     const unsigned long long lt = lanemask_lt();
     const unsigned wave = threadIdx.x >> 6;
     unsigned cbase = block_base + wave * kWfRaysPerWave;  // uniform per wave: next unassigned ray
@@ -813,34 +911,51 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
     Trav tr;
     tr.begin(mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f));
     tr.cur = Trav::kDone;
-    int idx = -1;        // local pixel index of the ray in flight
-    unsigned slot = 0;   // its position inside the block's range
+    unsigned pos = ~0u;          // stream position of the ray in flight (~0u: none)
+    unsigned npos = ~0u;         // prefetched next ray (~0u: none)
+    float4 nA = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 nB = make_float2(0.f, 1.f);
     WorkCount wc;
     for (;;) {
-        const unsigned long long idle = __ballot(tr.done());
-        if (idle != 0 && cbase < cend) {                  // refill idle lanes from the wave's range
-            const unsigned my = cbase + (unsigned)__popcll(idle & lt);
-            if (tr.done() && my < cend) {
-                idx = q[my];
-                slot = my - block_base;
-                const float4 a = w.sA[idx];
-                const float4 b = w.sB[idx];
-                tr.begin(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y));
-            }
-            cbase = min(cbase + (unsigned)__popcll(idle), cend);
+        // ---- lanes whose ray is finished switch to their prefetched ray
+        if (tr.done() && npos != ~0u) {
+            pos = npos;
+            npos = ~0u;
+            tr.begin(mk(nA.x, nA.y, nA.z), mk(nA.w, nB.x, nB.y));
         }
-        if (__ballot(!tr.done()) == 0) break;
-        tr.template round<unsigned, false>(sv, stk, &wc);
-        if (tr.done() && idx >= 0) {
-            float2* hitrec = reinterpret_cast<float2*>(&w.sB[idx]) + 1;
-            *hitrec = make_float2(tr.best_t, __int_as_float(tr.best));
+        // ---- lanes without a prefetched ray reserve the next positions of the wave's range
+        const unsigned long long want = __ballot(npos == ~0u);
+        if (want != 0 && cbase < cend) {
+            const unsigned my = cbase + (unsigned)__popcll(want & lt);
+            if (npos == ~0u && my < cend) {
+                npos = my;
+                nA = rsA[my];
+                nB = *reinterpret_cast<const float2*>(&rsB[my]);
+            }
+            cbase = min(cbase + (unsigned)__popcll(want), cend);
+        }
+        if (__ballot(!tr.done() || npos != ~0u) == 0) break;
+        // ---- one node visit, then one triangle test
+        if (tr.cur >= 0 && tr.cur != Trav::kDone) tr.template node_step<unsigned, false>(sv, stk, &wc);
+        if (tr.cur < 0) {
+            const int v = ~tr.cur;
+            const int first = v >> 3, count = (v & 7) + 1;
+            tr.template tri_step<false>(sv, first + tr.k, &wc);
+            if (++tr.k >= count) {
+                tr.k = 0;
+                tr.pop(stk);
+            }
+        }
+        // ---- finished: hit record + class byte
+        if (tr.done() && pos != ~0u) {
+            hits[pos] = make_float2(tr.best_t, __int_as_float(tr.best));
             int cls = 2;
             if (tr.best >= 0) {
                 const int type = p.mats[sv.meta[tr.best].mati].type;
                 cls = (type == 0 || type == 3) ? 0 : 1;
             }
-            lds_cls[slot] = (unsigned char)cls;
-            idx = -1;
+            lds_cls[pos - block_base] = (unsigned char)cls;
+            pos = ~0u;
         }
     }
     // ---- order-preserving compaction of the block's rays into the three class queues
@@ -871,7 +986,7 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
 #pragma unroll
     for (int k = 0; k < RPB / BLOCK; ++k) {
         const unsigned r = k * BLOCK + threadIdx.x;
-        if (cl[k] >= 0) w.q_cls[cl[k]][lds_base[cl[k]] + lds_cnt[(r >> 6) * 3 + cl[k]] + off[k]] = q[block_base + r];
+        if (cl[k] >= 0) w.q_cls[cl[k]][lds_base[cl[k]] + lds_cnt[(r >> 6) * 3 + cl[k]] + off[k]] = (int)(((unsigned)cost << 31) | (block_base + r));
     }
 }
 
@@ -887,8 +1002,13 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
     const unsigned i = blockIdx.x * kWfShadeBlock + threadIdx.x;
     int li = 0;
     int cost = -1;                                        // >= 0: the path continues with a ray of that cost class
+    f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
     if (i < n) {
-        li = w.q_cls[cls][i];
+        const unsigned e = (unsigned)w.q_cls[cls][i];
+        const int c_in = (int)(e >> 31);
+        const unsigned pos = e & 0x7fffffffu;
+        const float4 A = w.rsA[bounce & 1][c_in][pos], B = w.rsB[bounce & 1][c_in][pos];
+        li = __float_as_int(B.z);
         const float4 F = w.sF[li];
         f3 color = mk(F.x, F.y, F.z);
         const int sbits = __float_as_int(F.w);
@@ -897,17 +1017,15 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
         if (cls == 2) {                                   // miss: black environment, prog.cl:367-376
             wf_finalize(w, li, color, seed);
         } else {
-            const float4 A = w.sA[li], B = w.sB[li], C = w.sC[li], Dq = w.sD[li], E = w.sE[li];
-            f3 rP = mk(A.x, A.y, A.z), rD = mk(A.w, B.x, B.y);
+            const float2 h = w.hit[c_in][pos];
+            const float4 C = w.sC[li], Dq = w.sD[li], E = w.sE[li];
+            rP = mk(A.x, A.y, A.z);
+            rD = mk(A.w, B.x, B.y);
             f3 fL = mk(C.x, C.y, C.z), fB = mk(C.w, Dq.x, Dq.y), fS = mk(Dq.z, Dq.w, E.x), fR = mk(E.y, E.z, E.w);
-            const float t = B.z;
-            const int ti = __float_as_int(B.w);
-            shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, p.tris, p.meta, ti, t);
+            shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, p.tris, p.meta, __float_as_int(h.y), h.x);
             if (bounce + 1 >= p.iterations) {
                 wf_finalize(w, li, color, seed);
             } else {
-                w.sA[li] = make_float4(rP.x, rP.y, rP.z, rD.x);
-                w.sB[li] = make_float4(rD.y, rD.z, 0.0f, __int_as_float(-1));
                 w.sC[li] = make_float4(fL.x, fL.y, fL.z, fB.x);
                 w.sD[li] = make_float4(fB.y, fB.z, fS.x, fS.y);
                 w.sE[li] = make_float4(fS.z, fR.x, fR.y, fR.z);
@@ -916,8 +1034,31 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
             }
         }
     }
-    int32_t* queues[2] = {w.q_ray[(bounce + 1) & 1][0], w.q_ray[(bounce + 1) & 1][1]};
-    block_append<2, kWfShadeBlock>(cost, li, queues, w.counters + wf_row(bounce + 1) * kWfCounterStride, s_scratch);
+    const unsigned npos = block_reserve<2, kWfShadeBlock>(cost, w.counters + wf_row(bounce + 1) * kWfCounterStride, s_scratch);
+    if (cost >= 0) {
+        w.rsA[(bounce + 1) & 1][cost][npos] = make_float4(rP.x, rP.y, rP.z, rD.x);
+        w.rsB[(bounce + 1) & 1][cost][npos] = make_float4(rD.y, rD.z, __int_as_float(li), 0.0f);
+    }
+}
+
+// closest hit of arbitrary rays (test entry point): one ray per lane, packed triangle index out
+__global__ void __launch_bounds__(256) k_debug_closest_hit(RenderParams p, const pt_ray* rays, long long n, float* out_t, int* out_tri) {
+    LaneStack<unsigned> stk;
+    stk.base = reinterpret_cast<unsigned*>(pt_lds_raw) + threadIdx.x;
+    stk.stride = 256;
+    SceneView sv;
+    sv.nodes = p.nodes;
+    sv.tris = p.tris;
+    sv.meta = p.meta;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4* r = reinterpret_cast<const float4*>(&rays[i]);
+    const float4 a = r[0], b = r[1];
+    WorkCount wc;
+    float t;
+    const int ti = closest_hit<unsigned, false, false>(sv, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), stk, &t, &wc);
+    out_t[i] = ti >= 0 ? t : -1.0f;
+    out_tri[i] = ti;
 }
 
 // ---- tone mapping, prog.cl:247-269 (value of write_imagef at prog.cl:380)
@@ -1037,6 +1178,10 @@ static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc,
         case 1024: PT_LAUNCH(true, 1024, unsigned);
         }
     } else {
+        if (!SPLIT && !COUNT && lc.block == 256 && lc.traversal >= 2) {     // sliced traversal, slice = traversal - 1 rounds
+            hipLaunchKernelGGL((k_render_sliced<256, 4>), dim3(blocks), dim3(256), lds, stream, p, lc.traversal - 1);
+            return hipGetLastError();
+        }
         if (!SPLIT && lc.block == 256 && lc.traversal == 1) {               // voting schedule
             auto kern = k_render<SPLIT, false, 256, unsigned, COUNT, 4, true>;
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, p);
@@ -1083,6 +1228,12 @@ hipError_t launch_wf_intersect(const WfParams& w, int bounce, int, hipStream_t s
 
 hipError_t launch_wf_shade(const WfParams& w, int bounce, hipStream_t stream) {
     hipLaunchKernelGGL(wf_shade, dim3((w.npix + kWfShadeBlock - 1) / kWfShadeBlock, 3), dim3(kWfShadeBlock), 0, stream, w, bounce);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_debug_closest_hit, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)p.stack_entries * 4 * 256, stream, p, rays, (long long)n, out_t, out_tri);
     return hipGetLastError();
 }
 

@@ -41,10 +41,11 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
 
 if __name__ == "__main__":
     W, H = 1920, 1080
-    for n, b in ((100000, 8), (1000000, 16)):
-        spec = scenes.displaced_grid_mesh(n)
-        run(W, H, b, 4, spec, count=True, reps=1)
-        run(W, H, b, 8, spec, reps=2)
-        run(W, H, b, 8, spec, reps=2, variant=1)
     spec = scenes.cornell_box()
-    run(3840, 2160, 8, 8, spec, reps=2)
+    run(W, H, 8, 16, spec)
+    for tv in (2, 3, 4, 5, 7, 9):
+        run(W, H, 8, 16, spec, traversal=tv)
+    spec = scenes.displaced_grid_mesh(100000)
+    run(W, H, 8, 8, spec, reps=2)
+    for tv in (3, 5, 9):
+        run(W, H, 8, 8, spec, reps=2, traversal=tv)
