@@ -84,6 +84,7 @@ struct pt_context {
     int timing = 0;
     int count_work = 0;
     int traversal = 0;    // 0 while-while, 1 voting
+    int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
     int wf_blocks = 2048; // persistent grid of wf_intersect (256 CUs x 8 blocks of 256 threads)
     int min_waves = 4;    // k_render at 128 VGPRs (4 waves/SIMD) measured fastest
@@ -752,7 +753,12 @@ int pt_upload_materials(pt_context* ctx) {
         if (t.mati >= ctx->mats.size()) return fail(ctx, PT_EINVAL, "a triangle references a material index that was never added");
     if (ctx->has_device) {
         PT_HIP(ctx, hipSetDevice(ctx->device));
-        int rc = upload_vec(ctx, &ctx->d_mats, ctx->mats.data(), sizeof(pt_material) * ctx->mats.size());
+        // device copy: _pad marks materials whose specular lobe is identically zero (ks == 0, finite
+        // shininess >= 0): the kernel then skips pow(), the product ks*pow being +0 either way
+        std::vector<pt_material> dm(ctx->mats);
+        for (pt_material& m : dm)
+            m._pad = (m.ks.s[0] == 0.0f && m.ks.s[1] == 0.0f && m.ks.s[2] == 0.0f && std::isfinite(m.shininess) && m.shininess >= 0.0f) ? 1 : 0;
+        int rc = upload_vec(ctx, &ctx->d_mats, dm.data(), sizeof(pt_material) * dm.size());
         if (rc != PT_OK) return rc;
     }
     ctx->mats_uploaded = true;
@@ -1026,6 +1032,8 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         ctx->timing = value ? 1 : 0;
     } else if (k == "count_work") {
         ctx->count_work = value ? 1 : 0;
+    } else if (k == "debug_repeat") {
+        ctx->debug_repeat = (int)value;
     } else if (k == "cost_binning") {
         ctx->cost_binning = value ? 1 : 0;
     } else if (k == "traversal") {
@@ -1120,6 +1128,21 @@ int pt_debug_closest_hit(pt_context* ctx, const pt_ray* rays, int64_t n, float* 
     PT_HIP(ctx, hipMemcpy(d_rays, rays, sizeof(pt_ray) * (size_t)n, hipMemcpyHostToDevice));
     PT_HIP(ctx, launch_debug_closest_hit(p, d_rays, n, d_t, d_tri, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->debug_repeat > 0) {      // traversal-only timing: the same launch, debug_repeat times
+        hipEvent_t e0, e1;
+        PT_HIP(ctx, hipEventCreate(&e0));
+        PT_HIP(ctx, hipEventCreate(&e1));
+        PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        for (int r = 0; r < ctx->debug_repeat; ++r) PT_HIP(ctx, launch_debug_closest_hit(p, d_rays, n, d_t, d_tri, ctx->stream));
+        PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        PT_HIP(ctx, hipEventSynchronize(e1));
+        float ms = 0.f;
+        PT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        ctx->kernel_ms_acc += ms;
+        ctx->kernel_launches += ctx->debug_repeat;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
     PT_HIP(ctx, hipMemcpy(out_t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     PT_HIP(ctx, hipMemcpy(out_tri, d_tri, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; ++i)

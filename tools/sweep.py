@@ -42,10 +42,7 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
 if __name__ == "__main__":
     W, H = 1920, 1080
     spec = scenes.cornell_box()
-    run(W, H, 8, 16, spec)
-    for tv in (2, 3, 4, 5, 7, 9):
-        run(W, H, 8, 16, spec, traversal=tv)
-    spec = scenes.displaced_grid_mesh(100000)
-    run(W, H, 8, 8, spec, reps=2)
-    for tv in (3, 5, 9):
-        run(W, H, 8, 8, spec, reps=2, traversal=tv)
+    run(W, H, 8, 16, spec, reps=4)
+    run(W, H, 8, 64, spec, reps=2)
+    run(W, H, 8, 16, spec, reps=4, block=128)
+    run(W, H, 8, 16, spec, variant=1)
