@@ -84,6 +84,7 @@ struct pt_context {
     int timing = 0;
     int count_work = 0;
     int traversal = 0;    // 0 while-while, 1 voting
+    int pixel_map = 0;    // 0 tiles of 8x8 per wave, 1 strided (balances waves; for ranks with few waves)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
     int wf_blocks = 2048; // persistent grid of wf_intersect (256 CUs x 8 blocks of 256 threads)
@@ -485,6 +486,7 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->n_nodes = (int32_t)ctx->nodes.size();
     p->n_tris = (int32_t)ctx->orig.size();
     p->stack_entries = std::min(kStackEntries, ((ctx->bvh_depth + 2) + 1) & ~1);
+    p->pixel_map = ctx->pixel_map;
 }
 
 int check_ready(pt_context* ctx, const pt_camera* cam) {
@@ -1032,6 +1034,8 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         ctx->timing = value ? 1 : 0;
     } else if (k == "count_work") {
         ctx->count_work = value ? 1 : 0;
+    } else if (k == "pixel_map") {
+        ctx->pixel_map = value ? 1 : 0;
     } else if (k == "debug_repeat") {
         ctx->debug_repeat = (int)value;
     } else if (k == "cost_binning") {

@@ -61,6 +61,7 @@ struct RenderParams {
     int32_t n_nodes, n_tris;
     int32_t lds_scene;           // 1: stage nodes+triangles in LDS
     int32_t stack_entries;       // per-lane stack depth actually needed (BVH depth + 1)
+    int32_t pixel_map;           // 0: one wave = one 8x8 tile; 1: lane l of wave w owns pixel l*n_waves + w
 };
 
 // ---- wavefront (stream-compacted) formulation

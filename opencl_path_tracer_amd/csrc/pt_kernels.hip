@@ -155,6 +155,24 @@ struct PixelId {
 PT_DEV PixelId pixel_of_thread(const RenderParams& p) {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (p.pixel_map == 1) {
+        // strided map: every wave gets pixels from all over the rank's tile set, so that the total
+        // work per wave is nearly the same (matters when a rank has ~1 wave per SIMD slot: N >= 4)
+        const int npix = p.width * p.local_rows;
+        const int nw = (npix + 63) >> 6;
+        const int li = lane * nw + wave;
+        PixelId r;
+        if (wave >= nw || li >= npix) {
+            r.li = -1;
+            r.gid = 0;
+            return r;
+        }
+        const int lrow = li / p.width, x = li - lrow * p.width;
+        const int grow = ((lrow / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (lrow % p.rows_per_block);
+        r.li = li;
+        r.gid = grow * p.width + x;
+        return r;
+    }
     const int tiles_x = (p.width + 7) >> 3;
     const int ty = wave / tiles_x, tx = wave - ty * tiles_x;
     const int x = tx * 8 + (lane & 7);

@@ -348,6 +348,19 @@ def test_4k_frame_properties_c4(api, cb_spec):
     assert x_r == np.bitwise_xor.reduce(ra.view(np.uint32)) and x_c == np.bitwise_xor.reduce(ca.view(np.uint32).reshape(-1))
 
 
+def test_strided_pixel_map(api, oracle, cb_spec, cb_oracle_scene):
+    """pixel_map = 1 only changes which lane owns which pixel."""
+    W, H = 70, 45
+    for rank, world in ((0, 1), (1, 3)):
+        sc = api.Scene(W, H, rank=rank, world=world).load(cb_spec)
+        sc.set_option("pixel_map", 1)
+        sc.iterations = 6
+        sc.render(3)
+        fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 6, 3)
+        ids = sc.local_pixel_ids()
+        assert same_bits(sc.read_colors()[:, :3], fr.colors()[ids, :3]) and np.array_equal(sc.read_rnds(), fr.rnds()[ids])
+
+
 @pytest.mark.parametrize("tv", [1, 2, 4, 9])
 def test_traversal_schedules_identical(api, oracle, cb_spec, cb_oracle_scene, tv):
     """Scheduling variants of the render kernel (1 wave-voting, n >= 2 sliced traversal with n-1

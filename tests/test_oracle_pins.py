@@ -325,3 +325,124 @@ def test_golden_regression(oracle, cb_oracle_scene):
     assert np.array_equal(fr.colors()[:, :3].view(np.uint32), g["colors"].view(np.uint32))
     assert np.array_equal(fr.rnds(), g["rnds"])
     assert segs == int(g["segments"])
+
+
+def test_analytic_mirror_then_emitter(oracle):
+    """Camera -> mirror quad (type 1) -> emitter quad: color = emission * (1+1) * F * 1 * cos_e with
+    F = F0 + (1-F0)(1-|N.D|)^5 (prog.cl:219-222, 341-345, 358-366) evaluated independently in numpy."""
+    N = np.array([3.10, 3.05, 2.05], np.float32)
+    K = np.array([3.3, 3.3, 2.9], np.float32)
+    sc = oracle.OracleScene()
+    sc.add_Material((0, 0, 0), (0, 0, 0), (0, 0, 0), N, K, 0.0, 1)           # mirror ceiling at y = 3000
+    sc.add_Material((0, 0, 0), (0, 0, 0), (2.0, 3.0, 4.0), (0, 0, 0), (0, 0, 0), 0.0, 3)   # emitter floor at y = -3000
+    e = 1.0e6
+    sc.add_Triangle((-e, 3000, -e), (-e, 3000, e), (e, 3000, e), 0)
+    sc.add_Triangle((e, 3000, e), (e, 3000, -e), (-e, 3000, -e), 0)
+    sc.end_Obj()
+    sc.add_Triangle((-e, -3000, -e), (-e, -3000, e), (e, -3000, e), 1)
+    sc.add_Triangle((e, -3000, e), (e, -3000, -e), (-e, -3000, -e), 1)
+    sc.end_Obj()
+    W = H = 8
+    cam = oracle.make_camera(60.0, 0.0, -60.0, (0, 0, 0), W, H)              # looking up at the mirror
+    fr = oracle.OracleFrame(W, H)
+    fr.generate_rays(cam)
+    D = fr.rays()["D"][:, :3].astype(np.float64)
+    fr.trace_rays(sc, cam, 2, 0)                                              # two segments: mirror, emitter
+    cols = fr.colors()[:, :3].astype(np.float64)
+    up = D[:, 1] > 0
+    assert up.sum() > 32
+    F0 = ((K.astype(np.float64) ** 2 + (N.astype(np.float64) - 1) ** 2) / (K.astype(np.float64) ** 2 + (N.astype(np.float64) + 1) ** 2))
+    cosm = np.abs(D[:, 1])                      # |N.D| at the mirror; the reflected ray hits the floor with the same cosine
+    F = F0[None, :] + (1 - F0[None, :]) * ((1 - cosm) ** 5)[:, None]
+    want = np.array([2.0, 3.0, 4.0])[None, :] * 2.0 * F * cosm[:, None]
+    assert np.allclose(cols[up], want[up], rtol=3e-6)
+
+
+def test_analytic_diffuse_factor(oracle):
+    """One diffuse bounce then the lamp: color = E * (fL + fB) * cos_lamp with fL = kd * max(0, N.D'),
+    fB = ks * max(0, N.H)^shininess, H = normalize(view + D') (prog.cl:329-340, 358-366), where D' is the
+    cosine-sampled direction the oracle drew.  Recomputed from the rays buffer after one trace_rays."""
+    kd, ks, shin = (0.3, 0.2, 0.1), (0.3, 0.3, 0.3), 20.0
+    sc = oracle.OracleScene()
+    sc.add_Material(kd, ks, (0, 0, 0), (0, 0, 0), (0, 0, 0), shin, 0)         # diffuse floor far below
+    sc.add_Material((0, 0, 0), (0, 0, 0), (5.0, 5.0, 5.0), (0, 0, 0), (0, 0, 0), 0.0, 3)   # lamp ceiling
+    e = 1.0e6
+    sc.add_Triangle((-e, -2000, -e), (-e, -2000, e), (e, -2000, e), 0)
+    sc.add_Triangle((e, -2000, e), (e, -2000, -e), (-e, -2000, -e), 0)
+    sc.end_Obj()
+    sc.add_Triangle((-e, 4000, -e), (-e, 4000, e), (e, 4000, e), 1)
+    sc.add_Triangle((e, 4000, e), (e, 4000, -e), (-e, 4000, -e), 1)
+    sc.end_Obj()
+    W = H = 8
+    cam = oracle.make_camera(60.0, 0.0, 60.0, (0, 0, 0), W, H)                # looking down at the floor
+    fr = oracle.OracleFrame(W, H)
+    fr.generate_rays(cam)
+    D0 = fr.rays()["D"][:, :3].astype(np.float64)
+    eye = cam[0]["eye"][:3].astype(np.float64)
+    fr2 = oracle.OracleFrame(W, H)                                            # same seeds: 1 segment only -> rays = bounce ray
+    fr2.generate_rays(cam)
+    fr2.trace_rays(sc, cam, 1, 0)
+    D1 = fr2.rays()["D"][:, :3].astype(np.float64)
+    P1 = fr2.rays()["P"][:, :3].astype(np.float64)
+    fr.trace_rays(sc, cam, 2, 0)
+    cols = fr.colors()[:, :3].astype(np.float64)
+    down = D0[:, 1] < 0
+    assert down.sum() > 32
+    Nf = np.array([0.0, 1.0, 0.0])
+    idiff = np.maximum(0, D1 @ Nf)
+    view = eye[None, :] - P1                                                  # hit point ~ P1 (offset 1e-3 along N)
+    view /= np.linalg.norm(view, axis=1)[:, None]
+    Hh = view + D1
+    Hh /= np.linalg.norm(Hh, axis=1)[:, None]
+    ispec = np.maximum(0, Hh @ Nf)
+    fL = np.array(kd)[None, :] * idiff[:, None]
+    fB = np.array(ks)[None, :] * (ispec ** shin)[:, None]
+    coslamp = np.abs(D1[:, 1])
+    want = 5.0 * (fL + fB) * coslamp[:, None]
+    assert np.allclose(cols[down], want[down], rtol=2e-5)
+
+
+def test_analytic_dielectric_split(oracle):
+    """Camera -> glass plane (type 2, n = 1.5) -> emitter above (refracted path) or below (reflected
+    path): color = E * 2 * fR * cos_e with fR = (1-F)/(1-prob) on refraction, F/prob on reflection,
+    prob = mean(F) (prog.cl:228-245, 346-357); the refracted direction is D/n + N(cosa/n - sqrt(disc))."""
+    n = 1.5
+    sc = oracle.OracleScene()
+    sc.add_Material((0, 0, 0), (0, 0, 0), (0, 0, 0), (n, n, n), (0, 0, 0), 0.0, 2)
+    sc.add_Material((0, 0, 0), (0, 0, 0), (1.0, 2.0, 3.0), (0, 0, 0), (0, 0, 0), 0.0, 3)
+    e = 1.0e6
+    sc.add_Triangle((-e, 2000, -e), (-e, 2000, e), (e, 2000, e), 0)          # glass
+    sc.add_Triangle((e, 2000, e), (e, 2000, -e), (-e, 2000, -e), 0)
+    sc.end_Obj()
+    for y in (6000.0, -4000.0):                                               # emitters above and below
+        sc.add_Triangle((-e, y, -e), (-e, y, e), (e, y, e), 1)
+        sc.add_Triangle((e, y, e), (e, y, -e), (-e, y, -e), 1)
+        sc.end_Obj()
+    W = H = 16
+    cam = oracle.make_camera(50.0, 0.0, -55.0, (0, 0, 0), W, H)
+    a = oracle.OracleFrame(W, H)
+    a.generate_rays(cam)
+    D0 = a.rays()["D"][:, :3].astype(np.float64)
+    b = oracle.OracleFrame(W, H)
+    b.generate_rays(cam)
+    b.trace_rays(sc, cam, 1, 0)                                               # after the glass interaction only
+    D1 = b.rays()["D"][:, :3].astype(np.float64)
+    a.trace_rays(sc, cam, 2, 0)
+    cols = a.colors()[:, :3].astype(np.float64)
+    up = D0[:, 1] > 0.05
+    assert up.sum() > 200
+    F0 = ((n - 1) ** 2) / ((n + 1) ** 2)
+    cosa = np.abs(D0[:, 1])                       # N flipped against the ray: cosa = -D.N = |D.y|
+    F = F0 + (1 - F0) * (1 - cosa) ** 5
+    prob = F                                      # all three channels equal
+    refracted = D1[:, 1] > 0
+    assert refracted[up].any() and (~refracted[up]).any()          # both outcomes occur among 200+ pixels
+    fR = np.where(refracted, (1 - F) / (1 - prob), F / prob)
+    disc = 1 - (1 - cosa ** 2) / n / n
+    # refracted direction (flipped normal is -y): D/n + N*(cosa/n - sqrt(disc)), then normalised
+    Dr = D0 / n + np.array([0.0, -1.0, 0.0])[None, :] * (cosa / n - np.sqrt(disc))[:, None]
+    Dr /= np.linalg.norm(Dr, axis=1)[:, None]
+    assert np.allclose(D1[up & refracted], Dr[up & refracted], atol=2e-6)
+    cos_e = np.abs(D1[:, 1])
+    want = np.array([1.0, 2.0, 3.0])[None, :] * 2.0 * (fR * cos_e)[:, None]
+    assert np.allclose(cols[up], want[up], rtol=5e-6)
