@@ -15,6 +15,7 @@
 #include "pt_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -84,6 +85,8 @@ struct pt_context {
     int timing = 0;
     int count_work = 0;
     int traversal = 0;    // 0 while-while, 1 voting
+    int bvh_on_device = 0;
+    double bvh_build_ms = 0.0;
     int pixel_map = 0;    // 0 tiles of 8x8 per wave, 1 strided (balances waves; for ranks with few waves)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
@@ -334,6 +337,8 @@ Aabb padded_bounds(const pt_triangle& t) {
 }
 
 // One build attempt.  Returns PT_OK and fills bld.
+void compute_cost_boxes_impl(pt_context* ctx);
+
 int build_attempt(pt_context* ctx, BvhBuilder& bld, const std::vector<BuildPrim>& prims, int max_leaf, bool force_leaf) {
     bld = BvhBuilder();
     bld.prims = prims;
@@ -409,7 +414,22 @@ int build_and_pack(pt_context* ctx) {
     ctx->meta.resize(std::max<size_t>(m, 1));
     std::memset(ctx->packets.data(), 0, sizeof(TriPacket) * ctx->packets.size());
     std::memset(ctx->meta.data(), 0, sizeof(TriMeta) * ctx->meta.size());
-    // bounding boxes of the complex objects (more than 16 triangles), for the wavefront cost classes
+    compute_cost_boxes_impl(ctx);
+    for (size_t k = 0; k < m; ++k) {
+        const pt_triangle& t = ctx->tris[ctx->orig[k]];
+        float* v = ctx->packets[k].v;
+        v[0] = t.r1.s[0]; v[1] = t.r1.s[1]; v[2] = t.r1.s[2];
+        v[3] = t.r2.s[0]; v[4] = t.r2.s[1]; v[5] = t.r2.s[2];
+        v[6] = t.r3.s[0]; v[7] = t.r3.s[1]; v[8] = t.r3.s[2];
+        v[9] = t.N.s[0]; v[10] = t.N.s[1]; v[11] = t.N.s[2];
+        ctx->meta[k].rank = ctx->enc_rank[ctx->orig[k]];
+        ctx->meta[k].mati = t.mati;
+    }
+    return PT_OK;
+}
+
+// bounding boxes of the complex objects (more than 16 triangles), for the wavefront cost classes
+void compute_cost_boxes_impl(pt_context* ctx) {
     {
         struct OB { Aabb b; size_t n; };
         std::vector<OB> obs;
@@ -434,17 +454,6 @@ int build_and_pack(pt_context* ctx) {
             for (int a = 0; a < 3; ++a) ctx->cost_boxes.push_back(ob.b.hi[a]);
         }
     }
-    for (size_t k = 0; k < m; ++k) {
-        const pt_triangle& t = ctx->tris[ctx->orig[k]];
-        float* v = ctx->packets[k].v;
-        v[0] = t.r1.s[0]; v[1] = t.r1.s[1]; v[2] = t.r1.s[2];
-        v[3] = t.r2.s[0]; v[4] = t.r2.s[1]; v[5] = t.r2.s[2];
-        v[6] = t.r3.s[0]; v[7] = t.r3.s[1]; v[8] = t.r3.s[2];
-        v[9] = t.N.s[0]; v[10] = t.N.s[1]; v[11] = t.N.s[2];
-        ctx->meta[k].rank = ctx->enc_rank[ctx->orig[k]];
-        ctx->meta[k].mati = t.mati;
-    }
-    return PT_OK;
 }
 
 template <class T>
@@ -733,11 +742,63 @@ int pt_end_obj(pt_context* ctx) {
     return PT_OK;
 }
 
+// bvh_policy 4: build the tree on the device (pt_lbvh.hip); host copies are kept for the debug getters
+static int build_on_device(pt_context* ctx, bool* done) {
+    *done = false;
+    const int n = (int)ctx->tris.size();
+    if (!ctx->has_device || n <= 2 * kMaxLeaf) return PT_OK;
+    for (const pt_triangle& t : ctx->tris)
+        for (int a = 0; a < 3; ++a)
+            if (!std::isfinite(t.r1.s[a]) || !std::isfinite(t.r2.s[a]) || !std::isfinite(t.r3.s[a])) return PT_OK;   // host path handles those
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    LbvhResult r;
+    PT_HIP(ctx, lbvh_build(ctx->tris.data(), ctx->enc_rank.data(), n, ctx->stream, &r));
+    if (r.depth + 3 > kStackEntries) {          // deeper than the traversal stack: let the host builder do it
+        (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta); (void)hipFree(r.d_orig);
+        return PT_OK;
+    }
+    if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
+    if (ctx->d_tris) (void)hipFree(ctx->d_tris);
+    if (ctx->d_meta) (void)hipFree(ctx->d_meta);
+    ctx->d_nodes = r.d_nodes;
+    ctx->d_tris = r.d_tris;
+    ctx->d_meta = r.d_meta;
+    ctx->nodes.resize((size_t)r.n_nodes);
+    ctx->packets.resize((size_t)n);
+    ctx->meta.resize((size_t)n);
+    ctx->orig.resize((size_t)n);
+    PT_HIP(ctx, hipMemcpy(ctx->nodes.data(), r.d_nodes, sizeof(Node64) * (size_t)r.n_nodes, hipMemcpyDeviceToHost));
+    PT_HIP(ctx, hipMemcpy(ctx->packets.data(), r.d_tris, sizeof(TriPacket) * (size_t)n, hipMemcpyDeviceToHost));
+    PT_HIP(ctx, hipMemcpy(ctx->meta.data(), r.d_meta, sizeof(TriMeta) * (size_t)n, hipMemcpyDeviceToHost));
+    PT_HIP(ctx, hipMemcpy(ctx->orig.data(), r.d_orig, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(r.d_orig);
+    ctx->bvh_depth = r.depth + 1;
+    *done = true;
+    return PT_OK;
+}
+
+static void compute_cost_boxes(pt_context* ctx) { compute_cost_boxes_impl(ctx); }
+
 int pt_upload_triangles(pt_context* ctx) {
     if (!ctx) return PT_EINVAL;
     if (ctx->tri_shift != (int32_t)ctx->tris.size())
         return fail(ctx, PT_EINVAL, "triangles were added after the last end_Obj; close the object first (main.cpp:536)");
+    const auto t0 = std::chrono::steady_clock::now();
+    if (ctx->bvh_policy == 4) {
+        bool done = false;
+        int rcd = build_on_device(ctx, &done);
+        if (rcd != PT_OK) return rcd;
+        if (done) {
+            compute_cost_boxes(ctx);
+            ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            ctx->bvh_on_device = 1;
+            ctx->tris_uploaded = true;
+            return PT_OK;
+        }
+    }
+    ctx->bvh_on_device = 0;
     int rc = build_and_pack(ctx);
+    ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rc != PT_OK) return rc;
     if (ctx->has_device) {
         PT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1049,7 +1110,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "min_waves") {
         ctx->min_waves = (int)value;
     } else if (k == "bvh_policy") {
-        if (value < 0 || value > 3) return fail(ctx, PT_EINVAL, "bvh_policy must be 0..3");
+        if (value < 0 || value > 4) return fail(ctx, PT_EINVAL, "bvh_policy must be 0..4 (4 = device LBVH)");
         ctx->bvh_policy = (int)value;
         ctx->tris_uploaded = false;
     } else if (k == "reset_stats") {
@@ -1073,6 +1134,8 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out) {
     std::string k(key);
     if (k == "bvh_nodes") { *out = (double)ctx->nodes.size(); return PT_OK; }
     if (k == "bvh_depth") { *out = (double)ctx->bvh_depth; return PT_OK; }
+    if (k == "bvh_build_ms") { *out = ctx->bvh_build_ms; return PT_OK; }
+    if (k == "bvh_on_device") { *out = (double)ctx->bvh_on_device; return PT_OK; }
     if (k == "triangles") { *out = (double)ctx->orig.size(); return PT_OK; }
     if (k == "lds_bytes") { *out = (double)ctx->last_lds_bytes; return PT_OK; }
     if (k == "kernel_launches") { *out = (double)ctx->kernel_launches; return PT_OK; }

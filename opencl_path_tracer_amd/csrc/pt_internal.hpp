@@ -93,6 +93,17 @@ struct WfParams {
     int32_t sample;        // current_sample of this pass
 };
 
+// device-side BVH construction (pt_lbvh.hip); all pointers are device memory owned by the caller
+struct LbvhResult {
+    float4* d_nodes = nullptr;
+    int n_nodes = 0;
+    float4* d_tris = nullptr;
+    TriMeta* d_meta = nullptr;
+    int32_t* d_orig = nullptr;
+    int depth = 0;
+};
+hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, hipStream_t stream, LbvhResult* out);
+
 struct LaunchConfig {
     int block = 256;
     size_t lds_bytes = 0;

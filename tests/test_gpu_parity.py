@@ -425,3 +425,38 @@ def test_closest_hit_unit_level(api, oracle, cb_spec, cb_oracle_scene):
     N_gpu = tris_add_order["N"][tri[hitmask], :3]
     assert same_bits(N_gpu, h2["N"][hitmask, :3])
     assert np.array_equal(tris_add_order["mati"][tri[hitmask]], h2["mati"][hitmask])
+
+
+@pytest.mark.parametrize("which,ntris", [("cornell", 0), ("mesh", 6000), ("mesh", 100000)])
+def test_device_bvh_builder(api, oracle, cb_spec, cb_oracle_scene, which, ntris):
+    """bvh_policy 4: the tree is built ON THE DEVICE (LBVH: Morton codes, radix sort, Karras,
+    pt_lbvh.hip -- SURVEY 8f row 3).  The closest hit does not depend on the tree, so the render
+    must be bit-identical to the oracle just like with the host SAH builder; the emitted tree must
+    be a valid BVH over all triangles."""
+    import bvh_check
+    from opencl_path_tracer_amd import scenes
+    if which == "cornell":
+        spec, osc = cb_spec, cb_oracle_scene
+    else:
+        spec = scenes.displaced_grid_mesh(ntris)
+        osc = oracle.load_scene(spec)
+    W, H = 64, 48
+    sc = api.Scene(W, H)
+    sc.set_option("bvh_policy", 4)
+    sc.load(spec)
+    assert sc.stat("bvh_on_device") == 1
+    nodes, tris, meta, orig = sc.debug_bvh()
+    assert sorted(orig.tolist()) == list(range(spec.ntris))
+    if spec.ntris < 10000:
+        depth = bvh_check.validate_structure(nodes, tris, spec.ntris)
+        assert depth <= sc.stat("bvh_depth")
+    sc.iterations = 6
+    sc.render(2)
+    fr, segs = oracle_render(oracle, osc, spec, W, H, 6, 2)
+    check(sc, fr, "device bvh %s" % which)
+    assert sc.stat("segments") == segs
+    sc.set_option("variant", 1)
+    sc.current_sample = 0
+    sc.seed_default()
+    sc.render(2)
+    check(sc, fr, "device bvh wavefront %s" % which)
