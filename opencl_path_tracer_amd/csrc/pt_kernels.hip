@@ -288,7 +288,11 @@ struct Trav {
     }
     PT_DEV bool done() const { return cur == kDone; }
 
-    // one interior-node visit: slab-test both children, descend into the nearer hit one, push the other
+    // one interior-node visit: slab-test both children, descend into the nearer hit one, push the other.
+    // (plane - P) * inv keeps the relative error of each distance at ~2 ulp, which the 4-ulp widening
+    // covers.  Tried and rejected: the one-fma form plane*inv - P*inv (cancels; even with a per-ray
+    // error bound it culled a real hit in the parity suite, for +3 %), and float2-packed sub/mul
+    // (v_pk_add_f32 / v_pk_mul_f32 issue at half rate: no gain).
     template <class StackT, bool COUNT>
     PT_DEV void node_step(const SceneView& sv, const LaneStack<StackT> stk, WorkCount* wc) {
         const float kWiden = 1.0000005f;   // > 4 ulp: covers rcp + sub + mul rounding of the slab test
@@ -311,21 +315,21 @@ struct Trav {
         const bool hl = (lf >= ln) && (lf >= 0.0f) && (ln <= lim);
         const bool hr = (rf >= rn) && (rf >= 0.0f) && (rn <= lim);
         const int li = __float_as_int(qr.x), ri = __float_as_int(qr.y);
+        const bool lfirst = ln <= rn;
+        const bool take_left = hl && (!hr || lfirst);
+        int next = take_left ? li : ri;
         if (hl && hr) {
-            const bool lfirst = ln <= rn;
-            cur = lfirst ? li : ri;
-            stk.put(sp, lfirst ? ri : li);
+            stk.put(sp, take_left ? ri : li);
             ++sp;
-        } else if (hl) {
-            cur = li;
-        } else if (hr) {
-            cur = ri;
-        } else if (sp == 0) {
-            cur = kDone;
-        } else {
-            --sp;
-            cur = stk.get(sp);
         }
+        if (!(hl || hr)) {
+            next = kDone;
+            if (sp != 0) {
+                --sp;
+                next = stk.get(sp);
+            }
+        }
+        cur = next;
     }
 
     // exact test of packed triangle ti against the ray, keeping the closest (ties: lower rank)
