@@ -42,8 +42,8 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
 if __name__ == "__main__":
     W, H = 1920, 1080
     spec = scenes.cornell_box()
-    run(W, H, 8, 16, spec, reps=4)
-    run(W, H, 8, 16, spec, reps=4, min_waves=1)
     run(W, H, 8, 16, spec, variant=1)
+    run(W, H, 8, 16, spec, variant=1, ray_class_mode=1)
     spec = scenes.displaced_grid_mesh(100000)
-    run(W, H, 8, 8, spec, reps=2)
+    run(W, H, 8, 8, spec, reps=2, variant=1)
+    run(W, H, 8, 8, spec, reps=2, variant=1, ray_class_mode=1)
