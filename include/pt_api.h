@@ -135,12 +135,24 @@ int pt_bind_framebuffer(pt_context* ctx, void* d_colors, void* d_rnds);
 void* pt_device_colors(pt_context* ctx);
 void* pt_device_rnds(pt_context* ctx);
 int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStream_t; NULL = default stream */
-/* options: "variant" 0 = megakernel, 1 = wavefront; "block" threads per workgroup;
- * "lds_scene" 0/1 stage BVH+triangles in LDS when they fit; "timing" 0/1 HIP-event timing */
+/* options (key, value):
+ *   "variant"      0 megakernel (default), 1 wavefront (stream-compacted, path state in HBM)
+ *   "bvh_policy"   0 host SAH (default), 1-3 host variants (leaf policies), 4 device LBVH; set before upload
+ *   "lds_scene"    0/1 stage nodes + triangle packets in LDS when they fit (megakernel)
+ *   "block"        threads per workgroup of the megakernel (64..1024)
+ *   "min_waves"    __launch_bounds__ waves/SIMD of the megakernel (1,4,5,6,8; default 4)
+ *   "traversal"    0 while-while (default), 1 wave-voting, n >= 2 sliced (n-1 rounds per trip)
+ *   "pixel_map"    0 one wave = one 8x8 tile (default), 1 strided
+ *   "cost_binning" 0/1 wavefront: separate ray streams for rays touching a complex object's box
+ *   "timing"       0/1 record HIP events around the dominant kernel ("kernel_ms" statistic)
+ *   "count_work"   0/1 also count node visits / triangle tests (slower kernel instance)
+ *   "reset_stats"  1 zero all statistics
+ *   "debug_repeat" n extra timed launches in pt_debug_closest_hit */
 int pt_set_option(pt_context* ctx, const char* key, int64_t value);
-/* stats: "segments" path segments executed since the last reset, "samples", "kernel_ms"
- * (sum of HIP-event durations of the dominant kernel), "kernel_launches", "bvh_nodes",
- * "triangles", "lds_bytes", "reset" (write-only via pt_set_option("reset_stats",1)) */
+/* stats: "segments" path segments executed since the last reset, "samples", "kernel_ms" (sum of
+ * HIP-event durations of the dominant kernel), "kernel_launches", "bvh_nodes", "bvh_depth",
+ * "bvh_build_ms", "bvh_on_device", "triangles", "lds_bytes", and with count_work: "node_visits",
+ * "tri_tests", "wave_node_steps", "wave_tri_steps" */
 int pt_get_stat(pt_context* ctx, const char* key, double* out);
 
 /* ---- introspection for tests (host data; no device work) ----------------------------- */

@@ -90,7 +90,6 @@ struct pt_context {
     int pixel_map = 0;    // 0 tiles of 8x8 per wave, 1 strided (balances waves; for ranks with few waves)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
-    int wf_blocks = 2048; // persistent grid of wf_intersect (256 CUs x 8 blocks of 256 threads)
     int min_waves = 4;    // k_render at 128 VGPRs (4 waves/SIMD) measured fastest
     int bvh_policy = 0;   // 0 auto (SAH termination; LDS fit when lds_scene is on), 1 SAH termination, 2 leaves of <= 4, 3 leaves of <= 8
 
@@ -777,7 +776,7 @@ static int build_on_device(pt_context* ctx, bool* done) {
     return PT_OK;
 }
 
-static void compute_cost_boxes(pt_context* ctx) { compute_cost_boxes_impl(ctx); }
+static void compute_cost_boxes(pt_context* ctx) { compute_cost_boxes_impl(ctx); }   // defined in the anonymous namespace above
 
 int pt_upload_triangles(pt_context* ctx) {
     if (!ctx) return PT_EINVAL;
@@ -923,7 +922,6 @@ static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsa
     for (int b = 0; b < w.n_cbox; ++b)
         for (int k = 0; k < 6; ++k) w.cbox[b][k] = ctx->cost_boxes[(size_t)b * 6 + k];
     if (ctx->npix == 0) return PT_OK;
-    const int persistent_blocks = std::max(1, ctx->wf_blocks);
     for (int32_t k = 0; k < nsamples; ++k) {
         w.sample = rp.first_sample + k;
         PT_HIP(ctx, hipMemsetAsync(ctx->d_wf_counters, 0, sizeof(uint32_t) * kWfCounterStride, ctx->stream));
@@ -932,7 +930,7 @@ static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsa
             EventPair* ep;
             int rc = time_begin(ctx, &ep);
             if (rc != PT_OK) return rc;
-            PT_HIP(ctx, launch_wf_intersect(w, b, persistent_blocks, ctx->stream));
+            PT_HIP(ctx, launch_wf_intersect(w, b, ctx->stream));
             if ((rc = time_end(ctx, ep)) != PT_OK) return rc;
             PT_HIP(ctx, launch_wf_shade(w, b, ctx->stream));
         }
@@ -1104,9 +1102,6 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "traversal") {
         if (value < 0 || value > 64) return fail(ctx, PT_EINVAL, "traversal: 0 while-while, 1 voting, n >= 2 sliced with n-1 rounds per trip");
         ctx->traversal = (int)value;
-    } else if (k == "wf_blocks") {
-        if (value < 1 || value > 65535) return fail(ctx, PT_EINVAL, "wf_blocks out of range");
-        ctx->wf_blocks = (int)value;
     } else if (k == "min_waves") {
         ctx->min_waves = (int)value;
     } else if (k == "bvh_policy") {

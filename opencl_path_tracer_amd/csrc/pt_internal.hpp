@@ -119,7 +119,7 @@ hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hip
 hipError_t launch_resolve_reinhard(const float4* colors, float4* out, int64_t n, hipStream_t stream);
 hipError_t launch_filt_im(const float4* colors, float4* out, int32_t width, int32_t height, hipStream_t stream);
 hipError_t launch_wf_generate(const WfParams& p, hipStream_t stream);
-hipError_t launch_wf_intersect(const WfParams& p, int bounce, int grid_blocks, hipStream_t stream);
+hipError_t launch_wf_intersect(const WfParams& p, int bounce, hipStream_t stream);
 hipError_t launch_wf_shade(const WfParams& p, int bounce, hipStream_t stream);
 hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, hipStream_t stream);
 size_t mega_lds_bytes(const RenderParams& p, int block);

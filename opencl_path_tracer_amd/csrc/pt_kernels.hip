@@ -1244,7 +1244,7 @@ hipError_t launch_wf_generate(const WfParams& w, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_wf_intersect(const WfParams& w, int bounce, int, hipStream_t stream) {
+hipError_t launch_wf_intersect(const WfParams& w, int bounce, hipStream_t stream) {
     constexpr int BLOCK = 256, RPB = (BLOCK / 64) * kWfRaysPerWave;
     const size_t lds = (size_t)w.rp.stack_entries * 4 * BLOCK + RPB + (RPB / 64) * 3 * 4 + 32;
     hipLaunchKernelGGL(wf_intersect<BLOCK>, dim3((w.npix + RPB - 1) / RPB, 2), dim3(BLOCK), lds, stream, w, bounce);
