@@ -460,3 +460,31 @@ def test_device_bvh_builder(api, oracle, cb_spec, cb_oracle_scene, which, ntris)
     sc.seed_default()
     sc.render(2)
     check(sc, fr, "device bvh wavefront %s" % which)
+
+
+def test_closest_hit_unit_level_mesh(api, oracle):
+    """Same unit-level check on the 100k-triangle mesh scene with both builders: device result ==
+    exhaustive search == the reference's own traversal on 3,000 random rays."""
+    from opencl_path_tracer_amd import scenes
+    spec = scenes.displaced_grid_mesh(100000)
+    osc = oracle.load_scene(spec)
+    rng = np.random.RandomState(11)
+    n = 3000
+    P = np.stack([rng.uniform(-90, 1090, n), rng.uniform(5, 990, n), rng.uniform(-990, 990, n)], 1).astype(np.float32)
+    D = rng.normal(size=(n, 3))
+    D /= np.linalg.norm(D, axis=1)[:, None]
+    rays = np.zeros(n, dtype=api.RAY)
+    rays["P"][:, :3] = P
+    rays["D"][:, :3] = D.astype(np.float32)
+    h0 = osc.closest_hit(rays.view(oracle.RAY), mode=0)
+    h2 = osc.closest_hit(rays.view(oracle.RAY), mode=2)
+    ot0 = np.where(h0["t"] > 0, h0["t"], np.float32(-1))
+    ot2 = np.where(h2["t"] > 0, h2["t"], np.float32(-1))
+    assert same_bits(ot0, ot2)
+    for policy in (0, 4):
+        sc = api.Scene(16, 16)
+        sc.set_option("bvh_policy", policy)
+        sc.load(spec)
+        t, tri = sc.debug_closest_hit(rays)
+        assert same_bits(t, ot2), "bvh_policy %d" % policy
+        assert (tri >= 0).sum() > 2500
