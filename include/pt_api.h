@@ -138,7 +138,8 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
 /* options (key, value):
  *   "variant"      0 megakernel (default), 1 wavefront (stream-compacted, path state in HBM)
  *   "bvh_policy"   0 host SAH (default), 1-3 host variants (leaf policies), 4 device LBVH; set before upload
- *   "lds_scene"    0/1 stage nodes + triangle packets in LDS when they fit (megakernel)
+ *   "lds_scene"    megakernel: 2 (default) stage the BVH nodes in LDS when they fit (<= 64 KB, <= 4096
+ *                  triangles), 1 stage nodes and triangle packets, 0 everything through L1/L2
  *   "block"        threads per workgroup of the megakernel (64..1024)
  *   "min_waves"    __launch_bounds__ waves/SIMD of the megakernel (1,4,5,6,8; default 4)
  *   "traversal"    0 while-while (default), 1 wave-voting, n >= 2 sliced (n-1 rounds per trip)

@@ -81,13 +81,15 @@ struct pt_context {
     // ---- options
     int variant = 0;
     int block = 256;
-    int lds_scene = 0;   // staging the whole scene in LDS costs occupancy (1 block/CU); measured slower, off by default
+    int lds_scene = 2;   // 2: stage the BVH nodes in LDS when they fit next to two 512-thread blocks per CU (+5 %
+                         // measured); 1: nodes and packets (costs occupancy and needs a fat-leaf tree: slower); 0: off
     int timing = 0;
     int count_work = 0;
     int traversal = 0;    // 0 while-while, 1 voting
     int bvh_on_device = 0;
     double bvh_build_ms = 0.0;
     int pixel_map = 0;    // 0 tiles of 8x8 per wave, 1 strided (balances waves; for ranks with few waves)
+    int debug_lds_pad = 0; // extra LDS bytes per block of the timed debug launches (limits occupancy)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
     int min_waves = 4;    // k_render at 128 VGPRs (4 waves/SIMD) measured fastest
@@ -395,7 +397,7 @@ int build_and_pack(pt_context* ctx) {
     int rc = ctx->bvh_policy <= 1 ? build_attempt(ctx, bld, prims, 4, false)
                                   : build_attempt(ctx, bld, prims, ctx->bvh_policy == 2 ? 4 : 8, true);
     if (rc != PT_OK) return rc;
-    if (ctx->bvh_policy == 0 && ctx->lds_scene && footprint(bld) > lds_budget && sizeof(TriPacket) * prims.size() < lds_budget) {
+    if (ctx->bvh_policy == 0 && ctx->lds_scene == 1 && footprint(bld) > lds_budget && sizeof(TriPacket) * prims.size() < lds_budget) {
         const int tries[2][2] = {{4, 1}, {8, 1}};
         for (auto& t : tries) {
             BvhBuilder alt;
@@ -846,9 +848,9 @@ int pt_upload_seeds(pt_context* ctx, const int32_t* seeds, int64_t n) {
     return seed_upload(ctx, seeds);
 }
 
-static int launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc) {
-    lc->block = ctx->block;
-    lc->lds_bytes = mega_lds_bytes(p, ctx->block);
+static int launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc, int block) {
+    lc->block = block;
+    lc->lds_bytes = mega_lds_bytes(p, block);
     lc->count_work = ctx->count_work != 0;
     lc->min_waves = ctx->min_waves;
     lc->traversal = ctx->traversal;
@@ -856,7 +858,15 @@ static int launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc) 
     return PT_OK;
 }
 
-static void decide_lds_scene(const pt_context* ctx, RenderParams* p) {
+static void decide_lds_scene(const pt_context* ctx, RenderParams* p, int* block_out) {
+    *block_out = ctx->block;
+    if (ctx->lds_scene == 2) {      // nodes only: needs the 16-bit stack encoding and two 512-thread blocks per CU
+        const bool s16 = ctx->nodes.size() <= 32768 && ctx->orig.size() <= 4096;
+        const size_t need = sizeof(Node64) * ctx->nodes.size() + (size_t)p->stack_entries * 2 * 512 + 32;
+        p->lds_scene = (s16 && need <= 80 * 1024) ? 2 : 0;
+        if (p->lds_scene) *block_out = 512;
+        return;
+    }
     size_t scene = sizeof(Node64) * ctx->nodes.size() + sizeof(TriPacket) * ctx->orig.size();
     const bool s16 = ctx->nodes.size() <= 32768 && ctx->orig.size() <= 4096;
     size_t stack = (size_t)p->stack_entries * (s16 ? 2 : 4) * (size_t)ctx->block + 16;
@@ -887,9 +897,10 @@ int pt_trace_rays(pt_context* ctx, const pt_camera* cam, int32_t iterations, int
     p.iterations = iterations;
     p.first_sample = current_sample;
     p.nsamples = 1;
-    decide_lds_scene(ctx, &p);
+    int blk = ctx->block;
+    decide_lds_scene(ctx, &p, &blk);
     LaunchConfig lc;
-    launch_cfg(ctx, p, &lc);
+    launch_cfg(ctx, p, &lc, blk);
     EventPair* ep;
     if ((rc = time_begin(ctx, &ep)) != PT_OK) return rc;
     PT_HIP(ctx, launch_trace_ray(p, lc, ctx->stream));
@@ -960,9 +971,10 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         ctx->current_sample += nsamples;
         return PT_OK;
     }
-    decide_lds_scene(ctx, &p);
+    int blk = ctx->block;
+    decide_lds_scene(ctx, &p, &blk);
     LaunchConfig lc;
-    launch_cfg(ctx, p, &lc);
+    launch_cfg(ctx, p, &lc, blk);
     EventPair* ep;
     if ((rc = time_begin(ctx, &ep)) != PT_OK) return rc;
     PT_HIP(ctx, launch_render_mega(p, lc, ctx->stream));
@@ -1083,18 +1095,21 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return fail(ctx, PT_EINVAL, "block must be 64..1024, power of two");
         ctx->block = (int)value;
     } else if (k == "lds_scene") {
-        if ((value ? 1 : 0) != ctx->lds_scene && ctx->bvh_policy == 0 && ctx->tris_uploaded) {
-            ctx->lds_scene = value ? 1 : 0;          // the automatic BVH policy depends on it: rebuild
+        if (value < 0 || value > 2) return fail(ctx, PT_EINVAL, "lds_scene: 0 off, 1 nodes + packets in LDS, 2 nodes in LDS");
+        if ((value == 1) != (ctx->lds_scene == 1) && ctx->bvh_policy == 0 && ctx->tris_uploaded) {
+            ctx->lds_scene = (int)value;             // the automatic BVH policy depends on it: rebuild
             int rc = pt_upload_triangles(ctx);
             if (rc != PT_OK) return rc;
         }
-        ctx->lds_scene = value ? 1 : 0;
+        ctx->lds_scene = (int)value;
     } else if (k == "timing") {
         ctx->timing = value ? 1 : 0;
     } else if (k == "count_work") {
         ctx->count_work = value ? 1 : 0;
     } else if (k == "pixel_map") {
         ctx->pixel_map = value ? 1 : 0;
+    } else if (k == "debug_lds_pad") {
+        ctx->debug_lds_pad = (int)value;
     } else if (k == "debug_repeat") {
         ctx->debug_repeat = (int)value;
     } else if (k == "cost_binning") {
@@ -1195,7 +1210,7 @@ int pt_debug_closest_hit(pt_context* ctx, const pt_ray* rays, int64_t n, float* 
         PT_HIP(ctx, hipEventCreate(&e0));
         PT_HIP(ctx, hipEventCreate(&e1));
         PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
-        for (int r = 0; r < ctx->debug_repeat; ++r) PT_HIP(ctx, launch_debug_closest_hit(p, d_rays, n, d_t, d_tri, ctx->stream));
+        for (int r = 0; r < ctx->debug_repeat; ++r) PT_HIP(ctx, launch_debug_closest_hit(p, d_rays, n, d_t, d_tri, ctx->stream, (size_t)ctx->debug_lds_pad));
         PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
         PT_HIP(ctx, hipEventSynchronize(e1));
         float ms = 0.f;

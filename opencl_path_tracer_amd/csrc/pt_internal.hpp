@@ -121,7 +121,7 @@ hipError_t launch_filt_im(const float4* colors, float4* out, int32_t width, int3
 hipError_t launch_wf_generate(const WfParams& p, hipStream_t stream);
 hipError_t launch_wf_intersect(const WfParams& p, int bounce, hipStream_t stream);
 hipError_t launch_wf_shade(const WfParams& p, int bounce, hipStream_t stream);
-hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, hipStream_t stream);
+hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, hipStream_t stream, size_t lds_pad = 0);
 size_t mega_lds_bytes(const RenderParams& p, int block);
 int mega_max_lds_scene_bytes();
 

@@ -578,7 +578,9 @@ __global__ void __launch_bounds__(256) k_gen_ray(RenderParams p) {
 
 // The render kernel.  SPLIT = true: trace_ray alone (prog.cl:292-381), the ray comes from the
 // rays buffer and one sample is taken; SPLIT = false: nsamples x (gen_ray + trace_ray).
-template <bool SPLIT, bool LDS_SCENE, int BLOCK, class StackT, bool COUNT, int MINW, bool VOTE = false>
+// LDS_SCENE: 0 = nodes and packets through L1/L2; 1 = both staged in LDS; 2 = nodes staged in LDS,
+// packets through L1/L2 (the node loads are 3/4 of the traversal's gather instructions)
+template <bool SPLIT, int LDS_SCENE, int BLOCK, class StackT, bool COUNT, int MINW, bool VOTE = false>
 __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
     LaneStack<StackT> stk;
     stk.base = reinterpret_cast<StackT*>(pt_lds_raw) + threadIdx.x;          // [entry][lane]
@@ -595,9 +597,14 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
     if (LDS_SCENE) {
         float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + (size_t)p.stack_entries * sizeof(StackT) * BLOCK);
         float4* lds_tris = lds_nodes + p.n_nodes * 4;
-        stage_scene(p, lds_nodes, lds_tris);
+        if (LDS_SCENE == 1) {
+            stage_scene(p, lds_nodes, lds_tris);
+            sv.tris = lds_tris;
+        } else {
+            for (int i = threadIdx.x; i < p.n_nodes * 4; i += BLOCK) lds_nodes[i] = p.nodes[i];
+            __syncthreads();
+        }
         sv.nodes = lds_nodes;
-        sv.tris = lds_tris;
     }
     const PixelId px = pixel_of_thread(p);
     unsigned long long segs = 0, samples = 0;
@@ -1156,7 +1163,7 @@ static inline bool stack16_ok(const RenderParams& p) { return p.lds_scene && p.n
 size_t mega_lds_bytes(const RenderParams& p, int block) {
     size_t b = (size_t)p.stack_entries * (stack16_ok(p) ? 2 : 4) * (size_t)block;
     b = (b + 15) & ~(size_t)15;
-    if (p.lds_scene) b += (size_t)p.n_nodes * 64 + (size_t)p.n_tris * 48;
+    if (p.lds_scene) b += (size_t)p.n_nodes * 64 + (p.lds_scene == 1 ? (size_t)p.n_tris * 48 : 0);
     return b;
 }
 
@@ -1186,21 +1193,25 @@ static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc,
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(B), lds, stream, p);                           \
         return hipGetLastError();                                                                  \
     } while (0)
+    if (p.lds_scene == 2) {                 // nodes in LDS: two 512-thread workgroups per CU, 4 waves/SIMD
+        if (!stack16_ok(p) || lc.block != 512) return hipErrorInvalidValue;
+        PT_LAUNCH_W(2, 512, unsigned short, 4);
+    }
     if (p.lds_scene && stack16_ok(p)) {
         switch (lc.block) {
-        case 64: PT_LAUNCH(true, 64, unsigned short);
-        case 128: PT_LAUNCH(true, 128, unsigned short);
-        case 256: PT_LAUNCH(true, 256, unsigned short);
-        case 512: PT_LAUNCH(true, 512, unsigned short);
-        case 1024: PT_LAUNCH(true, 1024, unsigned short);
+        case 64: PT_LAUNCH(1, 64, unsigned short);
+        case 128: PT_LAUNCH(1, 128, unsigned short);
+        case 256: PT_LAUNCH(1, 256, unsigned short);
+        case 512: PT_LAUNCH(1, 512, unsigned short);
+        case 1024: PT_LAUNCH(1, 1024, unsigned short);
         }
     } else if (p.lds_scene) {
         switch (lc.block) {
-        case 64: PT_LAUNCH(true, 64, unsigned);
-        case 128: PT_LAUNCH(true, 128, unsigned);
-        case 256: PT_LAUNCH(true, 256, unsigned);
-        case 512: PT_LAUNCH(true, 512, unsigned);
-        case 1024: PT_LAUNCH(true, 1024, unsigned);
+        case 64: PT_LAUNCH(1, 64, unsigned);
+        case 128: PT_LAUNCH(1, 128, unsigned);
+        case 256: PT_LAUNCH(1, 256, unsigned);
+        case 512: PT_LAUNCH(1, 512, unsigned);
+        case 1024: PT_LAUNCH(1, 1024, unsigned);
         }
     } else {
         if (!SPLIT && !COUNT && lc.block == 256 && lc.traversal >= 2) {     // sliced traversal, slice = traversal - 1 rounds
@@ -1208,24 +1219,24 @@ static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc,
             return hipGetLastError();
         }
         if (!SPLIT && lc.block == 256 && lc.traversal == 1) {               // voting schedule
-            auto kern = k_render<SPLIT, false, 256, unsigned, COUNT, 4, true>;
+            auto kern = k_render<SPLIT, 0, 256, unsigned, COUNT, 4, true>;
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, p);
             return hipGetLastError();
         }
         if (!SPLIT && !COUNT && lc.block == 256 && lc.min_waves > 1) {      // occupancy experiments
             switch (lc.min_waves) {
-            case 4: PT_LAUNCH_W(false, 256, unsigned, 4);
-            case 5: PT_LAUNCH_W(false, 256, unsigned, 5);
-            case 6: PT_LAUNCH_W(false, 256, unsigned, 6);
-            case 8: PT_LAUNCH_W(false, 256, unsigned, 8);
+            case 4: PT_LAUNCH_W(0, 256, unsigned, 4);
+            case 5: PT_LAUNCH_W(0, 256, unsigned, 5);
+            case 6: PT_LAUNCH_W(0, 256, unsigned, 6);
+            case 8: PT_LAUNCH_W(0, 256, unsigned, 8);
             }
         }
         switch (lc.block) {
-        case 64: PT_LAUNCH(false, 64, unsigned);
-        case 128: PT_LAUNCH(false, 128, unsigned);
-        case 256: PT_LAUNCH(false, 256, unsigned);
-        case 512: PT_LAUNCH(false, 512, unsigned);
-        case 1024: PT_LAUNCH(false, 1024, unsigned);
+        case 64: PT_LAUNCH(0, 64, unsigned);
+        case 128: PT_LAUNCH(0, 128, unsigned);
+        case 256: PT_LAUNCH(0, 256, unsigned);
+        case 512: PT_LAUNCH(0, 512, unsigned);
+        case 1024: PT_LAUNCH(0, 1024, unsigned);
         }
     }
 #undef PT_LAUNCH
@@ -1256,9 +1267,54 @@ hipError_t launch_wf_shade(const WfParams& w, int bounce, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, hipStream_t stream) {
+// experiment: persistent traversal-only kernel with ALL BVH nodes staged in LDS (triangles stay
+// global); 512-thread blocks, 16-bit stack entries, grid-stride over the rays
+template <bool LDS_NODES>
+__global__ void __launch_bounds__(512) k_debug_closest_hit_persist(RenderParams p, const pt_ray* rays, long long n, float* out_t, int* out_tri) {
+    LaneStack<unsigned short> stk;
+    stk.base = reinterpret_cast<unsigned short*>(pt_lds_raw) + threadIdx.x;
+    stk.stride = 512;
+    SceneView sv;
+    sv.nodes = p.nodes;
+    sv.tris = p.tris;
+    sv.meta = p.meta;
+    if (LDS_NODES) {
+        float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + (((size_t)p.stack_entries * 2 * 512 + 15) & ~(size_t)15));
+        for (int i = threadIdx.x; i < p.n_nodes * 4; i += 512) lds_nodes[i] = p.nodes[i];
+        __syncthreads();
+        sv.nodes = lds_nodes;
+    }
+    WorkCount wc;
+    for (long long i = (long long)blockIdx.x * 512 + threadIdx.x; i < n; i += (long long)gridDim.x * 512) {
+        const float4* r = reinterpret_cast<const float4*>(&rays[i]);
+        const float4 a = r[0], b = r[1];
+        float t;
+        const int ti = closest_hit<unsigned short, false, false>(sv, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), stk, &t, &wc);
+        out_t[i] = ti >= 0 ? t : -1.0f;
+        out_tri[i] = ti;
+    }
+}
+
+hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, hipStream_t stream, size_t lds_pad) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_debug_closest_hit, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)p.stack_entries * 4 * 256, stream, p, rays, (long long)n, out_t, out_tri);
+    if (lds_pad == 1 || lds_pad == 2) {      // 1: persistent, nodes from global; 2: persistent, nodes in LDS
+        const bool in_lds = lds_pad == 2;
+        size_t lds = (((size_t)p.stack_entries * 2 * 512 + 15) & ~(size_t)15) + (in_lds ? (size_t)p.n_nodes * 64 : 0);
+        if (p.n_nodes > 32768 || p.n_tris > 4096 || lds > 80 * 1024) return hipErrorInvalidValue;
+        auto kern = in_lds ? k_debug_closest_hit_persist<true> : k_debug_closest_hit_persist<false>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(512), dim3(512), lds, stream, p, rays, (long long)n, out_t, out_tri);
+        return hipGetLastError();
+    }
+    const size_t lds = (size_t)p.stack_entries * 4 * 256 + lds_pad;    // lds_pad: occupancy experiments
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_debug_closest_hit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_debug_closest_hit, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream, p, rays, (long long)n, out_t, out_tri);
     return hipGetLastError();
 }
 

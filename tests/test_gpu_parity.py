@@ -82,7 +82,7 @@ def test_split_api_equals_fused(api, oracle, cb_spec, cb_oracle_scene):
     assert same_bits(r2["D"][:, :3], fr2.rays()["D"][:, :3]) and np.array_equal(c.read_rnds(), fr2.rnds())
 
 
-@pytest.mark.parametrize("lds,block", [(1, 256), (0, 256), (0, 64), (0, 512), (0, 1024), (1, 128)])
+@pytest.mark.parametrize("lds,block", [(1, 256), (0, 256), (0, 64), (0, 512), (0, 1024), (1, 128), (2, 256)])
 def test_variants_identical(api, oracle, cb_spec, cb_oracle_scene, lds, block):
     W, H = 96, 72
     sc = api.Scene(W, H).load(cb_spec)

@@ -42,10 +42,6 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
 if __name__ == "__main__":
     W, H = 1920, 1080
     spec = scenes.cornell_box()
-    run(W, H, 8, 16, spec, reps=2)
-    for cr in (1, 2, 3, 4, 6):
-        run(W, H, 8, 16, spec, reps=2, compact_rounds=cr)
-    spec = scenes.displaced_grid_mesh(100000)
-    run(W, H, 8, 8, spec, reps=2)
-    for cr in (2, 4, 6):
-        run(W, H, 8, 8, spec, reps=2, compact_rounds=cr)
+    run(W, H, 8, 16, spec, reps=3)
+    run(W, H, 8, 16, spec, reps=3, lds_scene=2)
+    run(W, H, 8, 16, spec, reps=3, block=512)
