@@ -88,6 +88,9 @@ struct pt_context {
     int traversal = 0;    // 0 while-while, 1 voting
     int bvh_on_device = 0;
     double bvh_build_ms = 0.0;
+    int cu_count = 256;
+    int persistent = 1;   // 1: megakernel waves pull tiles from a counter (grid = what fits the chip)
+    uint32_t* d_tile_counter = nullptr;
     int pixel_map = 0;    // 0 tiles of 8x8 per wave, 1 strided (balances waves; for ranks with few waves)
     int debug_lds_pad = 0; // extra LDS bytes per block of the timed debug launches (limits occupancy)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
@@ -497,6 +500,8 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->n_tris = (int32_t)ctx->orig.size();
     p->stack_entries = std::min(kStackEntries, ((ctx->bvh_depth + 2) + 1) & ~1);
     p->pixel_map = ctx->pixel_map;
+    p->tile_counter = nullptr;
+    p->n_tiles = ((ctx->W + 7) / 8) * ((ctx->local_rows + 7) / 8);
 }
 
 int check_ready(pt_context* ctx, const pt_camera* cam) {
@@ -645,6 +650,7 @@ int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->cu_count = prop.multiProcessorCount;
     std::snprintf(ctx->info, sizeof ctx->info, "%s (%s), %d CUs, %.1f GiB, wave %d", prop.name, prop.gcnArchName,
                   prop.multiProcessorCount, (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), prop.warpSize);
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -658,6 +664,7 @@ int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int
     if ((e = hipMalloc((void**)&ctx->d_rnds, sizeof(int32_t) * np)) != hipSuccess) return bail("hipMalloc(rnds)", e);     // main.cpp:509
     if ((e = hipMalloc((void**)&ctx->d_colors, sizeof(float4) * np)) != hipSuccess) return bail("hipMalloc(colors)", e);  // main.cpp:520
     if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * 8 * kStatRows)) != hipSuccess) return bail("hipMalloc(stats)", e);
+    if ((e = hipMalloc((void**)&ctx->d_tile_counter, 64)) != hipSuccess) return bail("hipMalloc(tile counter)", e);
     if ((e = hipMemset(ctx->d_rays, 0, sizeof(pt_ray) * np)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->d_colors, 0, sizeof(float4) * np)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8 * kStatRows)) != hipSuccess) return bail("hipMemset", e);
@@ -688,6 +695,7 @@ void pt_destroy(pt_context* ctx) {
         if (ctx->d_rays) (void)hipFree(ctx->d_rays);
         if (ctx->d_ldr) (void)hipFree(ctx->d_ldr);
         if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+        if (ctx->d_tile_counter) (void)hipFree(ctx->d_tile_counter);
         if (ctx->d_wf_state) (void)hipFree(ctx->d_wf_state);
         if (ctx->d_wf_queues) (void)hipFree(ctx->d_wf_queues);
         if (ctx->d_wf_counters) (void)hipFree(ctx->d_wf_counters);
@@ -854,6 +862,9 @@ static int launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc, 
     lc->count_work = ctx->count_work != 0;
     lc->min_waves = ctx->min_waves;
     lc->traversal = ctx->traversal;
+    // resident workgroups: 256 CUs x (2048 threads at 4 waves/SIMD ... the launcher's MINW decides; use
+    // the LDS/VGPR-limited count of the default configurations: 4 x 256-thread or 2 x 512-thread blocks)
+    lc->persistent_blocks = ctx->cu_count * std::max(1, 1024 / block);
     ctx->last_lds_bytes = lc->lds_bytes;
     return PT_OK;
 }
@@ -973,6 +984,10 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
     }
     int blk = ctx->block;
     decide_lds_scene(ctx, &p, &blk);
+    if (ctx->persistent) {
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counter, 0, sizeof(uint32_t), ctx->stream));
+        p.tile_counter = ctx->d_tile_counter;
+    }
     LaunchConfig lc;
     launch_cfg(ctx, p, &lc, blk);
     EventPair* ep;
@@ -1106,6 +1121,8 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         ctx->timing = value ? 1 : 0;
     } else if (k == "count_work") {
         ctx->count_work = value ? 1 : 0;
+    } else if (k == "persistent") {
+        ctx->persistent = value ? 1 : 0;
     } else if (k == "pixel_map") {
         ctx->pixel_map = value ? 1 : 0;
     } else if (k == "debug_lds_pad") {

@@ -61,6 +61,8 @@ struct RenderParams {
     int32_t n_nodes, n_tris;
     int32_t lds_scene;           // 1: stage nodes+triangles in LDS
     int32_t stack_entries;       // per-lane stack depth actually needed (BVH depth + 1)
+    uint32_t* tile_counter;      // != 0: persistent launch, waves pull tile indices from this counter
+    int32_t n_tiles;
     int32_t pixel_map;           // 0: one wave = one 8x8 tile; 1: lane l of wave w owns pixel l*n_waves + w
 };
 
@@ -109,6 +111,7 @@ struct LaunchConfig {
     size_t lds_bytes = 0;
     int min_waves = 1;         // __launch_bounds__ second argument (waves per SIMD the allocator must allow)
     int traversal = 0;         // 0 while-while rounds, 1 wave-voting single steps
+    int persistent_blocks = 1 << 30;   // grid size of a persistent launch (workgroups that fit the chip)
     bool count_work = false;   // also count node visits / triangle tests into stats[2], stats[3]
 };
 

@@ -152,9 +152,8 @@ struct PixelId {
     int li;   // local pixel index (buffer index), -1 = none
     int gid;  // global pixel id (what prog.cl calls id)
 };
-PT_DEV PixelId pixel_of_thread(const RenderParams& p) {
+PT_DEV PixelId pixel_of_wave(const RenderParams& p, int wave) {
     const int lane = threadIdx.x & 63;
-    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (p.pixel_map == 1) {
         // strided map: every wave gets pixels from all over the rank's tile set, so that the total
         // work per wave is nearly the same (matters when a rank has ~1 wave per SIMD slot: N >= 4)
@@ -187,6 +186,10 @@ PT_DEV PixelId pixel_of_thread(const RenderParams& p) {
     r.li = lrow * p.width + x;
     r.gid = grow * p.width + x;
     return r;
+}
+
+PT_DEV PixelId pixel_of_thread(const RenderParams& p) {
+    return pixel_of_wave(p, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
 }
 
 // ---------------------------------------------------------------------------- camera, prog.cl:82-92
@@ -606,9 +609,20 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
         }
         sv.nodes = lds_nodes;
     }
-    const PixelId px = pixel_of_thread(p);
     unsigned long long segs = 0, samples = 0;
     unsigned heavy16 = 0, heavy32 = 0, heavy32_nodes = 0;
+    // Persistent mode (p.tile_counter != 0): the grid only fills the machine, and every WAVE pulls the
+    // next 8x8 tile from a global counter as soon as it is done -- a wave never waits for the other
+    // waves of its workgroup, whose tiles may take 30 % longer (tiles over the spheres vs. bare walls).
+    int tile = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    for (;;) {
+    if (p.tile_counter) {
+        int t = 0;
+        if ((threadIdx.x & 63) == 0) t = (int)atomicAdd(p.tile_counter, 1u);
+        tile = __shfl(t, 0, 64);
+        if (tile >= p.n_tiles) break;
+    }
+    const PixelId px = pixel_of_wave(p, tile);
     if (px.li >= 0) {
         f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
         f3 fL = mk(1.f, 1.f, 1.f), fB = fL, fS = fL, fR = fL, color = mk(0.f, 0.f, 0.f);
@@ -675,6 +689,8 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
             r[0] = make_float4(rP.x, rP.y, rP.z, 0.0f);
             r[1] = make_float4(rD.x, rD.y, rD.z, 0.0f);
         }
+    }
+    if (!p.tile_counter) break;
     }
     segs = wave_sum(segs);
     samples = wave_sum(samples);
@@ -1180,7 +1196,8 @@ static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc,
     const int waves = n_waves(p);
     if (waves == 0) return hipSuccess;
     const int wpb = lc.block / 64;
-    const int blocks = (waves + wpb - 1) / wpb;
+    int blocks = (waves + wpb - 1) / wpb;
+    if (p.tile_counter) blocks = std::min(blocks, lc.persistent_blocks);
     const size_t lds = lc.lds_bytes;
 #define PT_LAUNCH(LDS, B, ST) PT_LAUNCH_W(LDS, B, ST, 1)
 #define PT_LAUNCH_W(LDS, B, ST, MW)                                                                \
