@@ -42,7 +42,5 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
 if __name__ == "__main__":
     W, H = 1920, 1080
     spec = scenes.cornell_box()
-    run(W, H, 8, 16, spec, reps=3, persistent=0)
-    run(W, H, 8, 16, spec, reps=3, persistent=1)
-    run(W, H, 8, 16, spec, reps=3, persistent=1, lds_scene=0)
-    run(W, H, 8, 16, spec, reps=3, persistent=0, lds_scene=0)
+    run(W, H, 8, 16, spec, reps=4, tile_lpt=0)
+    run(W, H, 8, 16, spec, reps=4, tile_lpt=1)
