@@ -611,6 +611,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
     }
     unsigned long long segs = 0, samples = 0;
     unsigned heavy16 = 0, heavy32 = 0, heavy32_nodes = 0;
+    unsigned long long segs_before_tile = 0, tile_lane_steps = 0;
     // Persistent mode (p.tile_counter != 0): the grid only fills the machine, and every WAVE pulls the
     // next 8x8 tile from a global counter as soon as it is done -- a wave never waits for the other
     // waves of its workgroup, whose tiles may take 30 % longer (tiles over the spheres vs. bare walls).
@@ -690,8 +691,15 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
             r[1] = make_float4(rD.x, rD.y, rD.z, 0.0f);
         }
     }
+    if (COUNT) {      // per tile: segment-steps the wave executed = 64 x the busiest lane's segments
+        unsigned long long mine = segs - segs_before_tile, mx = mine;
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned long long)__shfl_down(mx, off, 64));
+        if ((threadIdx.x & 63) == 0) tile_lane_steps += mx * 64ull;
+        segs_before_tile = segs;
+    }
     if (!p.tile_counter) break;
     }
+    if (COUNT && (threadIdx.x & 63) == 0 && p.stats) stat_add(p, 6, tile_lane_steps);
     segs = wave_sum(segs);
     samples = wave_sum(samples);
     if (COUNT) {
@@ -703,9 +711,9 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
             stat_add(p, 4, wwn);
             stat_add(p, 5, wwt);
         }
-        const unsigned long long h16 = wave_sum((unsigned long long)heavy16), h32 = wave_sum(((unsigned long long)heavy32_nodes << 24) | heavy32);
+        const unsigned long long h32 = wave_sum(((unsigned long long)heavy32_nodes << 24) | heavy32);
+        (void)heavy16;
         if ((threadIdx.x & 63) == 0 && p.stats) {
-            stat_add(p, 6, h16);
             stat_add(p, 7, h32);
         }
     }

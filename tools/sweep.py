@@ -30,9 +30,7 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
     if count:
         nv, tt, wn, wt = sc.stat("node_visits"), sc.stat("tri_tests"), sc.stat("wave_node_steps"), sc.stat("wave_tri_steps")
         wsegs = segs / 64.0
-        h16, h32p = sc.stat("heavy16"), int(sc.stat("heavy32"))
-        h32, h32n = h32p & 0xFFFFFF, h32p >> 24
-        print("   segments with >16 node visits: %.1f%%; >32: %.2f%% (packed counters wrap; indicative only) mean nodes of >32: %.1f" % (100 * h16 / segs, 100.0 * h32 / max(segs, 1), h32n / max(h32, 1)))
+        print("   per-tile lane balance (lane segments / 64 x busiest lane): %.1f%%" % (100 * segs / max(sc.stat("tile_lane_steps"), 1)))
         extra = "  nodes/seg=%.2f tris/seg=%.2f | per wave-segment: node body x%.1f (util %.0f%%), tri body x%.1f (util %.0f%%)" % (
             nv / segs, tt / segs, wn / wsegs, 100 * nv / (64 * wn), wt / wsegs, 100 * tt / (64 * wt))
     print("%dx%d b%d spp%d %-45s nodes=%d lds_bytes=%6d: %8.1f Msamples/s (kernel %8.1f)  dbar=%.3f  Mseg/s=%.1f%s" % (
