@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the path-tracing hot path on MI355X.
 
 Metric (BASELINE.json): Msamples/s, whole job, at 1920x1080, 8 bounces, Cornell box
-(config 2: 1,024 spp at the default --steps 64 x 16 spp).  A sample is one camera path of up
+(config 2: 1,024 spp at the default --steps 16 x 64 spp).  A sample is one camera path of up
 to 8 segments.  One "step" = one pass of the hot path (gen_ray + trace_ray, fused) taking
 --spp-per-step samples of every pixel of the frame.
 
@@ -44,9 +44,9 @@ BYTES_PER_SAMPLE = 32.0          # colors 16 B R + 16 B W
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--bounces", type=int, default=BOUNCES)

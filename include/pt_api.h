@@ -145,6 +145,8 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *   "traversal"    0 while-while (default), 1 wave-voting, n >= 2 sliced (n-1 rounds per trip)
  *   "persistent"   1 (default) megakernel grid only fills the chip and every wave pulls its next 8x8
  *                  tile from a global counter; 0 one workgroup per group of tiles
+ *   "chunk_spp"    persistent megakernel work items: n > 0 (pass, tile) items of n samples, chained per tile
+ *                  through memory inside ONE launch; 0 whole tiles; -1 (default) automatic
  *   "pixel_map"    0 one wave = one 8x8 tile (default), 1 strided
  *   "cost_binning" 0/1 wavefront: separate ray streams for rays touching a complex object's box
  *   "timing"       0/1 record HIP events around the dominant kernel ("kernel_ms" statistic)

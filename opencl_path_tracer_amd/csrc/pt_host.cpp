@@ -91,6 +91,9 @@ struct pt_context {
     int cu_count = 256;
     int persistent = 1;   // 1: megakernel waves pull tiles from a counter (grid = what fits the chip)
     uint32_t* d_tile_counter = nullptr;
+    uint32_t* d_tile_done = nullptr;
+    int chunk_spp = -1;   // persistent megakernel work items: > 0 (pass, tile) items of that many samples, 0 whole
+                          // tiles, -1 automatic (4 when the context has clearly more tiles than resident waves)
     int pixel_map = 0;    // 0 tiles of 8x8 per wave, 1 strided (balances waves; for ranks with few waves)
     int debug_lds_pad = 0; // extra LDS bytes per block of the timed debug launches (limits occupancy)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
@@ -501,6 +504,8 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->stack_entries = std::min(kStackEntries, ((ctx->bvh_depth + 2) + 1) & ~1);
     p->pixel_map = ctx->pixel_map;
     p->tile_counter = nullptr;
+    p->chunk_spp = 0;
+    p->tile_done = nullptr;
     p->n_tiles = ((ctx->W + 7) / 8) * ((ctx->local_rows + 7) / 8);
 }
 
@@ -696,6 +701,7 @@ void pt_destroy(pt_context* ctx) {
         if (ctx->d_ldr) (void)hipFree(ctx->d_ldr);
         if (ctx->d_stats) (void)hipFree(ctx->d_stats);
         if (ctx->d_tile_counter) (void)hipFree(ctx->d_tile_counter);
+        if (ctx->d_tile_done) (void)hipFree(ctx->d_tile_done);
         if (ctx->d_wf_state) (void)hipFree(ctx->d_wf_state);
         if (ctx->d_wf_queues) (void)hipFree(ctx->d_wf_queues);
         if (ctx->d_wf_counters) (void)hipFree(ctx->d_wf_counters);
@@ -987,6 +993,17 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
     if (ctx->persistent) {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counter, 0, sizeof(uint32_t), ctx->stream));
         p.tile_counter = ctx->d_tile_counter;
+        // automatic: chaining passes only pays when there are enough tiles to re-balance; with about one
+        // tile per resident wave (a 1080p frame over 8 GPUs) the most expensive tile is the critical path
+        // either way and the extra hand-offs cost 2-4 %
+        const int resident_waves = ctx->cu_count * 16;
+        const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : (p.n_tiles > resident_waves + resident_waves / 2 ? 4 : 0);
+        if (chunk > 0 && nsamples > chunk && p.n_tiles > 0) {
+            if (!ctx->d_tile_done) PT_HIP(ctx, hipMalloc((void**)&ctx->d_tile_done, sizeof(uint32_t) * (size_t)p.n_tiles));
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_done, 0, sizeof(uint32_t) * (size_t)p.n_tiles, ctx->stream));
+            p.tile_done = ctx->d_tile_done;
+            p.chunk_spp = chunk;
+        }
     }
     LaunchConfig lc;
     launch_cfg(ctx, p, &lc, blk);
@@ -1121,6 +1138,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         ctx->timing = value ? 1 : 0;
     } else if (k == "count_work") {
         ctx->count_work = value ? 1 : 0;
+    } else if (k == "chunk_spp") {
+        if (value < -1 || value > 1 << 20) return fail(ctx, PT_EINVAL, "chunk_spp out of range");
+        ctx->chunk_spp = (int)value;
     } else if (k == "persistent") {
         ctx->persistent = value ? 1 : 0;
     } else if (k == "pixel_map") {

@@ -63,6 +63,9 @@ struct RenderParams {
     int32_t stack_entries;       // per-lane stack depth actually needed (BVH depth + 1)
     uint32_t* tile_counter;      // != 0: persistent launch, waves pull tile indices from this counter
     int32_t n_tiles;
+    int32_t chunk_spp;           // > 0: a work item is (pass, tile) = chunk_spp samples of a tile; passes of one
+                                 // tile are chained through tile_done[] (agent-scope release / acquire)
+    uint32_t* tile_done;         // [n_tiles] number of passes completed, zeroed before the launch
     int32_t pixel_map;           // 0: one wave = one 8x8 tile; 1: lane l of wave w owns pixel l*n_waves + w
 };
 

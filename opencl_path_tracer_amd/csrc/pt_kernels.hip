@@ -615,14 +615,39 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
     // Persistent mode (p.tile_counter != 0): the grid only fills the machine, and every WAVE pulls the
     // next 8x8 tile from a global counter as soon as it is done -- a wave never waits for the other
     // waves of its workgroup, whose tiles may take 30 % longer (tiles over the spheres vs. bare walls).
+    // With p.chunk_spp > 0 a work item is (pass, tile): chunk_spp samples of one tile.  Items are handed
+    // out in pass-major order, so the producer of a tile's previous pass was dequeued n_tiles items
+    // earlier by a resident wave (no deadlock); its rnds/colors reach this wave -- possibly on another
+    // XCD -- through an agent-scope release (producer) / acquire (consumer) around tile_done[tile].
     int tile = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    int pass = 0;
+    const int n_pass = p.chunk_spp > 0 ? (p.nsamples + p.chunk_spp - 1) / p.chunk_spp : 1;
     for (;;) {
     if (p.tile_counter) {
         int t = 0;
         if ((threadIdx.x & 63) == 0) t = (int)atomicAdd(p.tile_counter, 1u);
-        tile = __shfl(t, 0, 64);
-        if (tile >= p.n_tiles) break;
+        t = __shfl(t, 0, 64);
+        if (p.chunk_spp > 0) {
+            pass = t / p.n_tiles;
+            tile = t - pass * p.n_tiles;
+            if (pass >= n_pass) break;
+            if (pass > 0) {
+                unsigned seen = 0;
+                for (;;) {
+                    if ((threadIdx.x & 63) == 0) seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    seen = __shfl(seen, 0, 64);
+                    if (seen >= (unsigned)pass) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        } else {
+            tile = t;
+            if (tile >= p.n_tiles) break;
+        }
     }
+    const int item_first = p.first_sample + (p.chunk_spp > 0 ? pass * p.chunk_spp : 0);
+    const int item_end = p.chunk_spp > 0 ? min(item_first + p.chunk_spp, p.first_sample + p.nsamples) : p.first_sample + p.nsamples;
     const PixelId px = pixel_of_wave(p, tile);
     if (px.li >= 0) {
         f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
@@ -630,12 +655,12 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
         bool inside = false;
         int seed = p.rnds[px.li];
         f3 acc = mk(0.0f, 0.0f, 0.0f);
-        if (p.first_sample != 0) {             // prog.cl:312-314: sample 0 starts from black
+        if (item_first != 0) {                 // prog.cl:312-314: sample 0 starts from black
             const float4 c = p.colors[px.li];
             acc = mk(c.x, c.y, c.z);
         }
-        int s = p.first_sample;
-        const int s_end = p.first_sample + p.nsamples;
+        int s = item_first;
+        const int s_end = item_end;
         int bounce = 0;
         bool fresh = true;
         for (;;) {
@@ -696,6 +721,12 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
         for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned long long)__shfl_down(mx, off, 64));
         if ((threadIdx.x & 63) == 0) tile_lane_steps += mx * 64ull;
         segs_before_tile = segs;
+    }
+    if (p.tile_counter && p.chunk_spp > 0) {
+        // publish this pass of the tile: every lane's stores -> L2 write-back -> counter
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(&p.tile_done[tile], (unsigned)(pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!p.tile_counter) break;
     }

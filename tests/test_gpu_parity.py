@@ -361,6 +361,39 @@ def test_strided_pixel_map(api, oracle, cb_spec, cb_oracle_scene):
         assert same_bits(sc.read_colors()[:, :3], fr.colors()[ids, :3]) and np.array_equal(sc.read_rnds(), fr.rnds()[ids])
 
 
+@pytest.mark.parametrize("chunk,W,H,bounces,spp", [(1, 96, 72, 8, 5), (2, 50, 37, 5, 7), (4, 256, 256, 4, 16), (3, 1, 1, 4, 5), (2, 33, 65, 0, 4)])
+def test_chained_passes_in_one_launch(api, oracle, cb_spec, cb_oracle_scene, chunk, W, H, bounces, spp):
+    """chunk_spp > 0: the persistent launch hands out (pass, tile) items; a tile's passes may run on
+    different CUs / XCDs and hand rnds/colors over through memory with agent-scope release/acquire.
+    Every pixel is compared, so a single stale word would show."""
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.set_option("chunk_spp", chunk)
+    sc.iterations = bounces
+    sc.render(spp)
+    fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, bounces, spp)
+    check(sc, fr, "chunk_spp=%d" % chunk)
+    assert sc.stat("segments") == segs and sc.stat("samples") == W * H * spp
+
+
+def test_chained_passes_full_size_stress(api, cb_spec):
+    """1920x1080, 8 bounces, 12 samples as 12 chained single-sample passes in one launch (388,800
+    tile hand-offs, most of them between different CUs) == the same render without chaining, bit for
+    bit, three times over (timing differs from run to run)."""
+    W, H = 1920, 1080
+    a = api.Scene(W, H).load(cb_spec)
+    a.set_option("chunk_spp", 0)
+    a.iterations = 8
+    a.render(12)
+    ca, ra = a.read_colors(), a.read_rnds()
+    for chunk in (1, 1, 3):
+        b = api.Scene(W, H).load(cb_spec)
+        b.set_option("chunk_spp", chunk)
+        b.iterations = 8
+        b.render(12)
+        assert same_bits(ca, b.read_colors()) and np.array_equal(ra, b.read_rnds())
+        del b
+
+
 @pytest.mark.parametrize("tv", [1, 2, 4, 9])
 def test_traversal_schedules_identical(api, oracle, cb_spec, cb_oracle_scene, tv):
     """Scheduling variants of the render kernel (1 wave-voting, n >= 2 sliced traversal with n-1

@@ -26,10 +26,10 @@ def t_rank(world, rank, rb=8, **opts):
 
 base = t_rank(1, 0)
 print("1 rank : %.3f s  (%.1f Msamples/s)" % (base, W * H * SPP * STEPS / base / 1e6), flush=True)
-b1 = t_rank(1, 0, pixel_map=1)
-print("1 rank strided: %.3f s  (%.1f Msamples/s)" % (b1, W * H * SPP * STEPS / b1 / 1e6), flush=True)
+b1 = t_rank(1, 0, chunk_spp=4)
+print("1 rank chunk 4: %.3f s  (%.1f Msamples/s)" % (b1, W * H * SPP * STEPS / b1 / 1e6), flush=True)
 for world in (2, 4, 8):
-    for opts in ({}, {"pixel_map": 1}):
+    for opts in ({}, {"chunk_spp": 4}, {"chunk_spp": 2}):
         ts = [t_rank(world, r, **opts) for r in sorted(set([0, world // 2, world - 1]))]
         worst = max(ts)
         print("%d ranks %-18s: rank times %s -> efficiency %.1f%% vs tile-map N=1 (render only)" % (world, opts, ["%.3f" % x for x in ts], 100 * base / (world * worst)), flush=True)

@@ -40,5 +40,7 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
 if __name__ == "__main__":
     W, H = 1920, 1080
     spec = scenes.cornell_box()
-    run(W, H, 8, 16, spec, reps=4, tile_lpt=0)
-    run(W, H, 8, 16, spec, reps=4, tile_lpt=1)
+    run(W, H, 8, 16, spec, reps=4)
+    for c in (8, 4, 2, 1):
+        run(W, H, 8, 16, spec, reps=4, chunk_spp=c)
+    run(W, H, 8, 64, spec, reps=2, chunk_spp=4)
