@@ -1194,14 +1194,14 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out) {
         *out = ctx->kernel_ms_acc;
         return PT_OK;
     }
-    if (k == "segments" || k == "samples" || k == "node_visits" || k == "tri_tests" || k == "wave_node_steps" || k == "wave_tri_steps" || k == "tile_lane_steps" || k == "heavy32") {
+    if (k == "segments" || k == "samples" || k == "node_visits" || k == "tri_tests" || k == "wave_node_steps" || k == "wave_tri_steps" || k == "tile_lane_steps") {
         std::vector<unsigned long long> rows((size_t)8 * kStatRows);
         unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         PT_HIP(ctx, hipMemcpy(rows.data(), ctx->d_stats, sizeof(unsigned long long) * rows.size(), hipMemcpyDeviceToHost));
         for (int r = 0; r < kStatRows; ++r)
             for (int c = 0; c < 8; ++c) h[c] += rows[(size_t)r * 8 + c];
-        *out = (double)h[k == "segments" ? 0 : k == "samples" ? 1 : k == "node_visits" ? 2 : k == "tri_tests" ? 3 : k == "wave_node_steps" ? 4 : k == "wave_tri_steps" ? 5 : k == "tile_lane_steps" ? 6 : 7];
+        *out = (double)h[k == "segments" ? 0 : k == "samples" ? 1 : k == "node_visits" ? 2 : k == "tri_tests" ? 3 : k == "wave_node_steps" ? 4 : k == "wave_tri_steps" ? 5 : 6];
         return PT_OK;
     }
     return fail(ctx, PT_EINVAL, "unknown stat: " + k);

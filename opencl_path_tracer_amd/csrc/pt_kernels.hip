@@ -579,10 +579,85 @@ __global__ void __launch_bounds__(256) k_gen_ray(RenderParams p) {
     r[1] = make_float4(D.x, D.y, D.z, 0.0f);
 }
 
-// The render kernel.  SPLIT = true: trace_ray alone (prog.cl:292-381), the ray comes from the
-// rays buffer and one sample is taken; SPLIT = false: nsamples x (gen_ray + trace_ray).
+// All samples [s_begin, s_end) of ONE pixel, path state in registers: nsamples x (gen_ray + trace_ray).
+// SPLIT: trace_ray alone (prog.cl:292-381) -- the ray comes from, and is left in, the rays buffer.
+template <bool SPLIT, class StackT, bool COUNT, bool VOTE>
+PT_DEV void render_pixel(const RenderParams& p, const SceneView& sv, const LaneStack<StackT> stk, const PixelId px,
+                         int s_begin, int s_end, unsigned long long* segs, unsigned long long* samples, WorkCount* wc) {
+    f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
+    f3 fL = mk(1.f, 1.f, 1.f), fB = fL, fS = fL, fR = fL, color = mk(0.f, 0.f, 0.f);
+    bool inside = false;
+    int seed = p.rnds[px.li];
+    f3 acc = mk(0.0f, 0.0f, 0.0f);
+    if (s_begin != 0) {                        // prog.cl:312-314: sample 0 starts from black
+        const float4 c = p.colors[px.li];
+        acc = mk(c.x, c.y, c.z);
+    }
+    int s = s_begin;
+    int bounce = 0;
+    bool fresh = true;
+    for (;;) {
+        if (fresh) {                           // a lane whose path ended starts its next sample right here
+            if (s == s_end) break;
+            fL = mk(1.f, 1.f, 1.f);            // prog.cl:307-316
+            fB = fL;
+            fS = fL;
+            fR = fL;
+            color = mk(0.f, 0.f, 0.f);
+            inside = false;
+            if (SPLIT) {
+                const float4* r = reinterpret_cast<const float4*>(&p.rays[px.li]);
+                const float4 a = r[0], b = r[1];
+                rP = mk(a.x, a.y, a.z);
+                rD = mk(b.x, b.y, b.z);
+            } else {
+                const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+                camera_get_ray(px.gid, p.cam, rnd1, rnd2, &rP, &rD);
+            }
+            bounce = 0;
+            fresh = false;
+        }
+        bool finished = true;
+        if (bounce < p.iterations) {
+            float t;
+            const int ti = closest_hit<StackT, COUNT, VOTE>(sv, rP, rD, stk, &t, wc);
+            ++*segs;
+            if (ti >= 0) {
+                shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, ti, t);
+                ++bounce;
+                finished = (bounce >= p.iterations);
+            }
+        }
+        if (finished) {
+            acc = running_mean(acc, color, s);
+            ++s;
+            ++*samples;
+            fresh = true;
+        }
+    }
+    p.colors[px.li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    p.rnds[px.li] = seed;
+    if (SPLIT) {
+        float4* r = reinterpret_cast<float4*>(&p.rays[px.li]);
+        r[0] = make_float4(rP.x, rP.y, rP.z, 0.0f);
+        r[1] = make_float4(rD.x, rD.y, rD.z, 0.0f);
+    }
+}
+
+// The render kernel.  One wave = one 8x8 pixel tile; each lane owns one pixel.
 // LDS_SCENE: 0 = nodes and packets through L1/L2; 1 = both staged in LDS; 2 = nodes staged in LDS,
-// packets through L1/L2 (the node loads are 3/4 of the traversal's gather instructions)
+// packets through L1/L2 (the node loads are 3/4 of the traversal's gather instructions).
+//
+// Launch modes:
+//  * plain (p.tile_counter == 0): wave w of the grid renders tile w, all samples.
+//  * persistent (p.tile_counter != 0): the grid only fills the machine and every WAVE pulls its next
+//    work item from a global counter as soon as it is done -- it never waits for the other waves of
+//    its workgroup, whose tiles may take 30 % longer (tiles over the spheres vs. bare walls).
+//  * persistent with chained passes (p.chunk_spp > 0): a work item is (pass, tile) = chunk_spp
+//    samples of one tile, handed out pass-major.  The producer of a tile's previous pass was dequeued
+//    n_tiles items earlier by a resident wave, so waiting for it cannot deadlock; its rnds/colors
+//    reach this wave -- possibly on another XCD -- through an agent-scope release (producer: stores,
+//    L2 write-back, tile_done[tile] = pass + 1) and acquire (consumer: poll, L1 invalidate, loads).
 template <bool SPLIT, int LDS_SCENE, int BLOCK, class StackT, bool COUNT, int MINW, bool VOTE = false>
 __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
     LaneStack<StackT> stk;
@@ -609,146 +684,62 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
         }
         sv.nodes = lds_nodes;
     }
-    unsigned long long segs = 0, samples = 0;
-    unsigned heavy16 = 0, heavy32 = 0, heavy32_nodes = 0;
-    unsigned long long segs_before_tile = 0, tile_lane_steps = 0;
-    // Persistent mode (p.tile_counter != 0): the grid only fills the machine, and every WAVE pulls the
-    // next 8x8 tile from a global counter as soon as it is done -- a wave never waits for the other
-    // waves of its workgroup, whose tiles may take 30 % longer (tiles over the spheres vs. bare walls).
-    // With p.chunk_spp > 0 a work item is (pass, tile): chunk_spp samples of one tile.  Items are handed
-    // out in pass-major order, so the producer of a tile's previous pass was dequeued n_tiles items
-    // earlier by a resident wave (no deadlock); its rnds/colors reach this wave -- possibly on another
-    // XCD -- through an agent-scope release (producer) / acquire (consumer) around tile_done[tile].
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    const bool chained = p.tile_counter != nullptr && p.chunk_spp > 0;
+    const int n_pass = chained ? (p.nsamples + p.chunk_spp - 1) / p.chunk_spp : 1;
+    unsigned long long segs = 0, samples = 0, segs_before_item = 0, item_lane_steps = 0;
     int tile = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     int pass = 0;
-    const int n_pass = p.chunk_spp > 0 ? (p.nsamples + p.chunk_spp - 1) / p.chunk_spp : 1;
     for (;;) {
-    if (p.tile_counter) {
-        int t = 0;
-        if ((threadIdx.x & 63) == 0) t = (int)atomicAdd(p.tile_counter, 1u);
-        t = __shfl(t, 0, 64);
-        if (p.chunk_spp > 0) {
-            pass = t / p.n_tiles;
+        if (p.tile_counter) {                                    // ---- fetch the next work item
+            int t = 0;
+            if (lane0) t = (int)atomicAdd(p.tile_counter, 1u);
+            t = __shfl(t, 0, 64);
+            pass = chained ? t / p.n_tiles : 0;
             tile = t - pass * p.n_tiles;
-            if (pass >= n_pass) break;
-            if (pass > 0) {
+            if (chained ? pass >= n_pass : tile >= p.n_tiles) break;
+            if (pass > 0) {                                      // ---- acquire the tile's previous pass
                 unsigned seen = 0;
                 for (;;) {
-                    if ((threadIdx.x & 63) == 0) seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane0) seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     seen = __shfl(seen, 0, 64);
                     if (seen >= (unsigned)pass) break;
                     __builtin_amdgcn_s_sleep(8);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
-        } else {
-            tile = t;
-            if (tile >= p.n_tiles) break;
         }
-    }
-    const int item_first = p.first_sample + (p.chunk_spp > 0 ? pass * p.chunk_spp : 0);
-    const int item_end = p.chunk_spp > 0 ? min(item_first + p.chunk_spp, p.first_sample + p.nsamples) : p.first_sample + p.nsamples;
-    const PixelId px = pixel_of_wave(p, tile);
-    if (px.li >= 0) {
-        f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
-        f3 fL = mk(1.f, 1.f, 1.f), fB = fL, fS = fL, fR = fL, color = mk(0.f, 0.f, 0.f);
-        bool inside = false;
-        int seed = p.rnds[px.li];
-        f3 acc = mk(0.0f, 0.0f, 0.0f);
-        if (item_first != 0) {                 // prog.cl:312-314: sample 0 starts from black
-            const float4 c = p.colors[px.li];
-            acc = mk(c.x, c.y, c.z);
+        const int s_begin = p.first_sample + (chained ? pass * p.chunk_spp : 0);
+        const int s_end = chained ? min(s_begin + p.chunk_spp, p.first_sample + p.nsamples) : p.first_sample + p.nsamples;
+        const PixelId px = pixel_of_wave(p, tile);
+        if (px.li >= 0) render_pixel<SPLIT, StackT, COUNT, VOTE>(p, sv, stk, px, s_begin, s_end, &segs, &samples, &wc);
+        if (COUNT) {      // segment-steps the wave executed for this item = 64 x the busiest lane's segments
+            unsigned long long mx = segs - segs_before_item;
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned long long)__shfl_down(mx, off, 64));
+            if (lane0) item_lane_steps += mx * 64ull;
+            segs_before_item = segs;
         }
-        int s = item_first;
-        const int s_end = item_end;
-        int bounce = 0;
-        bool fresh = true;
-        for (;;) {
-            if (fresh) {
-                if (s == s_end) break;
-                fL = mk(1.f, 1.f, 1.f);        // prog.cl:307-316
-                fB = fL;
-                fS = fL;
-                fR = fL;
-                color = mk(0.f, 0.f, 0.f);
-                inside = false;
-                if (SPLIT) {
-                    const float4* r = reinterpret_cast<const float4*>(&p.rays[px.li]);
-                    const float4 a = r[0], b = r[1];
-                    rP = mk(a.x, a.y, a.z);
-                    rD = mk(b.x, b.y, b.z);
-                } else {
-                    const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
-                    camera_get_ray(px.gid, p.cam, rnd1, rnd2, &rP, &rD);
-                }
-                bounce = 0;
-                fresh = false;
-            }
-            bool finished = true;
-            if (bounce < p.iterations) {
-                float t;
-                const unsigned nodes_before = wc.nodes;
-                const int ti = closest_hit<StackT, COUNT, VOTE>(sv, rP, rD, stk, &t, &wc);
-                if (COUNT) {
-                    const unsigned dn = wc.nodes - nodes_before;
-                    if (dn > 16) { heavy16++; }
-                    if (dn > 32) { heavy32++; heavy32_nodes += dn; }
-                }
-                ++segs;
-                if (ti >= 0) {
-                    shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, ti, t);
-                    ++bounce;
-                    finished = (bounce >= p.iterations);
-                }
-            }
-            if (finished) {
-                acc = running_mean(acc, color, s);
-                ++s;
-                ++samples;
-                fresh = true;
-            }
+        if (chained) {                                           // ---- release this pass of the tile
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // keep the wait the compiler may drop (guide, G16)
+            if (lane0) __hip_atomic_store(&p.tile_done[tile], (unsigned)(pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        p.colors[px.li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-        p.rnds[px.li] = seed;
-        if (SPLIT) {
-            float4* r = reinterpret_cast<float4*>(&p.rays[px.li]);
-            r[0] = make_float4(rP.x, rP.y, rP.z, 0.0f);
-            r[1] = make_float4(rD.x, rD.y, rD.z, 0.0f);
-        }
+        if (!p.tile_counter) break;
     }
-    if (COUNT) {      // per tile: segment-steps the wave executed = 64 x the busiest lane's segments
-        unsigned long long mine = segs - segs_before_tile, mx = mine;
-        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned long long)__shfl_down(mx, off, 64));
-        if ((threadIdx.x & 63) == 0) tile_lane_steps += mx * 64ull;
-        segs_before_tile = segs;
-    }
-    if (p.tile_counter && p.chunk_spp > 0) {
-        // publish this pass of the tile: every lane's stores -> L2 write-back -> counter
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((threadIdx.x & 63) == 0) __hip_atomic_store(&p.tile_done[tile], (unsigned)(pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (!p.tile_counter) break;
-    }
-    if (COUNT && (threadIdx.x & 63) == 0 && p.stats) stat_add(p, 6, tile_lane_steps);
     segs = wave_sum(segs);
     samples = wave_sum(samples);
     if (COUNT) {
         const unsigned long long wn = wave_sum((unsigned long long)wc.nodes), wt = wave_sum((unsigned long long)wc.tris);
         const unsigned long long wwn = wave_sum((unsigned long long)wc.wnodes), wwt = wave_sum((unsigned long long)wc.wtris);
-        if ((threadIdx.x & 63) == 0 && p.stats) {
+        if (lane0 && p.stats) {
             stat_add(p, 2, wn);
             stat_add(p, 3, wt);
             stat_add(p, 4, wwn);
             stat_add(p, 5, wwt);
-        }
-        const unsigned long long h32 = wave_sum(((unsigned long long)heavy32_nodes << 24) | heavy32);
-        (void)heavy16;
-        if ((threadIdx.x & 63) == 0 && p.stats) {
-            stat_add(p, 7, h32);
+            stat_add(p, 6, item_lane_steps);
         }
     }
-    if ((threadIdx.x & 63) == 0 && p.stats) {
+    if (lane0 && p.stats) {
         stat_add(p, 0, segs);
         stat_add(p, 1, samples);
     }
