@@ -39,8 +39,10 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
 
 if __name__ == "__main__":
     W, H = 1920, 1080
+    for n, b in ((100000, 8), (1000000, 16)):
+        spec = scenes.displaced_grid_mesh(n)
+        run(W, H, b, 16, spec, reps=2)
+        run(W, H, b, 16, spec, reps=2, variant=1)
     spec = scenes.cornell_box()
-    run(W, H, 8, 16, spec, reps=4)
-    for c in (8, 4, 2, 1):
-        run(W, H, 8, 16, spec, reps=4, chunk_spp=c)
-    run(W, H, 8, 64, spec, reps=2, chunk_spp=4)
+    run(3840, 2160, 8, 16, spec, reps=2)
+    run(256, 256, 4, 16, spec, reps=4)
