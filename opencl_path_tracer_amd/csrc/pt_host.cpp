@@ -396,7 +396,7 @@ int build_and_pack(pt_context* ctx) {
     // if it makes the whole scene fit the LDS of one CU next to the traversal stacks.
     const size_t lds_budget = 160 * 1024;
     auto footprint = [&](const BvhBuilder& b) {
-        int entries = std::min(kStackEntries, ((b.max_depth_seen + 2) + 1) & ~1);
+        int entries = std::min(kStackEntries, ((b.max_depth_seen + 4) + 1) & ~1);
         return sizeof(Node64) * b.nodes.size() + sizeof(TriPacket) * b.order.size() + (size_t)entries * 4 * 256;
     };
     BvhBuilder bld;
@@ -501,7 +501,7 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->rows_per_block = ctx->rows_per_block;
     p->n_nodes = (int32_t)ctx->nodes.size();
     p->n_tris = (int32_t)ctx->orig.size();
-    p->stack_entries = std::min(kStackEntries, ((ctx->bvh_depth + 2) + 1) & ~1);
+    p->stack_entries = std::min(kStackEntries, ((ctx->bvh_depth + 4) + 1) & ~1);   // sentinel + far children + the slot above the top (Trav::node_step)
     p->pixel_map = ctx->pixel_map;
     p->tile_counter = nullptr;
     p->chunk_spp = 0;
@@ -768,7 +768,7 @@ static int build_on_device(pt_context* ctx, bool* done) {
     PT_HIP(ctx, hipSetDevice(ctx->device));
     LbvhResult r;
     PT_HIP(ctx, lbvh_build(ctx->tris.data(), ctx->enc_rank.data(), n, ctx->stream, &r));
-    if (r.depth + 3 > kStackEntries) {          // deeper than the traversal stack: let the host builder do it
+    if (r.depth + 5 > kStackEntries) {          // deeper than the traversal stack: let the host builder do it
         (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta); (void)hipFree(r.d_orig);
         return PT_OK;
     }
@@ -878,14 +878,14 @@ static int launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc, 
 static void decide_lds_scene(const pt_context* ctx, RenderParams* p, int* block_out) {
     *block_out = ctx->block;
     if (ctx->lds_scene == 2) {      // nodes only: needs the 16-bit stack encoding and two 512-thread blocks per CU
-        const bool s16 = ctx->nodes.size() <= 32768 && ctx->orig.size() <= 4096;
+        const bool s16 = ctx->nodes.size() <= 32767 && ctx->orig.size() <= 4096;
         const size_t need = sizeof(Node64) * ctx->nodes.size() + (size_t)p->stack_entries * 2 * 512 + 32;
         p->lds_scene = (s16 && need <= 80 * 1024) ? 2 : 0;
         if (p->lds_scene) *block_out = 512;
         return;
     }
     size_t scene = sizeof(Node64) * ctx->nodes.size() + sizeof(TriPacket) * ctx->orig.size();
-    const bool s16 = ctx->nodes.size() <= 32768 && ctx->orig.size() <= 4096;
+    const bool s16 = ctx->nodes.size() <= 32767 && ctx->orig.size() <= 4096;
     size_t stack = (size_t)p->stack_entries * (s16 ? 2 : 4) * (size_t)ctx->block + 16;
     p->lds_scene = (ctx->lds_scene && scene + stack <= (size_t)mega_max_lds_scene_bytes()) ? 1 : 0;
 }

@@ -41,7 +41,7 @@ struct TriMeta {
 constexpr int kMaxLeaf = 4;        // triangles per leaf (<= 8 by the reference encoding)
 constexpr int kMaxDepth = 30;      // builder guarantees depth <= kMaxDepth
 constexpr int kStatRows = 256;     // statistics counters are spread over this many rows of 8
-constexpr int kStackEntries = 32;  // upper bound of the per-lane traversal stack (far children only)
+constexpr int kStackEntries = 36;  // upper bound of the per-lane traversal stack: sentinel + far children + one slot above the top
 
 // ---- kernel parameter block (passed by value, like `Camera` in prog.cl:292-304) ----------
 struct RenderParams {

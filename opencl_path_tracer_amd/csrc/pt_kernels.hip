@@ -236,23 +236,12 @@ PT_DEV float tri_test(const float4 a, const float4 b, const float4 c, f3 P, f3 V
 }
 
 // Per-lane traversal stack in LDS, laid out [entry][lane] (consecutive lanes -> consecutive
-// banks).  Small scenes (the ones that are LDS-resident) use 16-bit entries so that 16 waves per
-// CU fit next to the staged scene: interior index < 2^15, or 0x8000 | (first << 3 | count-1).
+// banks).  Entry 0 holds a "finished" sentinel, so popping never has to test for an empty stack.
+// Scenes whose nodes are staged in LDS use 16-bit entries (16 waves per CU fit next to the nodes).
 template <class T>
 struct LaneStack {
     T* base;        // already offset by the lane
     int stride;     // entries are `stride` elements apart
-    PT_DEV void put(int sp, int ref) const {
-        if (sizeof(T) == 2) base[sp * stride] = (T)(ref >= 0 ? ref : (0x8000 | (~ref)));
-        else base[sp * stride] = (T)ref;
-    }
-    PT_DEV int get(int sp) const {
-        if (sizeof(T) == 2) {
-            const int e = (int)base[sp * stride];
-            return (e & 0x8000) ? ~(e & 0x7fff) : e;
-        }
-        return (int)base[sp * stride];
-    }
 };
 
 struct WorkCount {
@@ -270,69 +259,108 @@ PT_DEV bool first_active_lane() {
 // until it holds a leaf (or has finished), then all lanes holding leaves intersect them.  The
 // per-lane state survives between rounds so that a persistent kernel can hand a finished lane
 // its next ray while the others keep going.
+//
+// Node references (`cur`, child slots, stack entries):
+//   StackT = unsigned        nodes read from global memory as the host packed them:
+//                            >= 0 interior index, < 0 leaf ~(first << 3 | count - 1), kDone finished
+//   StackT = unsigned short  nodes staged in LDS by stage_nodes(), which also re-encodes the child
+//                            slots to 16 bits: < 0x7fff interior index, 0x7fff finished,
+//                            0x8000 | (first << 3 | count - 1) leaf -- nothing to encode or decode on
+//                            a push or pop -- and swizzles the box quads (see node_step).
+template <class StackT>
 struct Trav {
+    static constexpr bool kSel = sizeof(StackT) == 2;
+    static constexpr int kDone = kSel ? 0x7fff : 0x7fffffff;
     f3 P, D, inv;
     float best_t;
-    int best;   // packed triangle index of the closest hit so far, -1 none
-    int sp;
-    int cur;    // >= 0 interior node (the root always is one); < 0 leaf reference; kDone finished
-    int k;      // voting schedule: next triangle of the current leaf
-    static constexpr int kDone = 0x7fffffff;
+    int best;      // packed triangle index of the closest hit so far, -1 none
+    char* tos;     // top of this lane's stack (entry 0 = sentinel kDone), as a byte address
+    int stride;    // bytes between entries
+    int cur;
+    int k;         // single-step schedules: next triangle of the current leaf
+    int onx, ony, onz;   // kSel: byte offset of the entry-plane pair of each axis inside a node
 
-    PT_DEV void begin(f3 P_, f3 D_) {
+    PT_DEV static bool is_node(int c) { return kSel ? c < 0x7fff : (unsigned)c < 0x7fffffffu; }
+    PT_DEV static bool is_leaf(int c) { return kSel ? c > 0x7fff : c < 0; }
+    PT_DEV static int leaf_bits(int c) { return kSel ? (c & 0x7fff) : ~c; }
+
+    PT_DEV void begin(f3 P_, f3 D_, const LaneStack<StackT> stk) {
         P = P_;
         D = D_;
         inv = mk(__builtin_amdgcn_rcpf(D_.x), __builtin_amdgcn_rcpf(D_.y), __builtin_amdgcn_rcpf(D_.z));
         best_t = __builtin_inff();
         best = -1;
-        sp = 0;
-        cur = 0;
+        tos = reinterpret_cast<char*>(stk.base);
+        stride = stk.stride * (int)sizeof(StackT);
+        *reinterpret_cast<StackT*>(tos) = (StackT)kDone;
+        cur = 0;        // the root is always an interior node
         k = 0;
+        onx = __float_as_int(inv.x) < 0 ? 8 : 0;
+        ony = __float_as_int(inv.y) < 0 ? 24 : 16;
+        onz = __float_as_int(inv.z) < 0 ? 40 : 32;
     }
+    PT_DEV void idle() { cur = kDone; }
     PT_DEV bool done() const { return cur == kDone; }
 
-    // one interior-node visit: slab-test both children, descend into the nearer hit one, push the other.
-    // (plane - P) * inv keeps the relative error of each distance at ~2 ulp, which the 4-ulp widening
-    // covers.  Tried and rejected: the one-fma form plane*inv - P*inv (cancels; even with a per-ray
-    // error bound it culled a real hit in the parity suite, for +3 %), and float2-packed sub/mul
-    // (v_pk_add_f32 / v_pk_mul_f32 issue at half rate: no gain).
-    template <class StackT, bool COUNT>
-    PT_DEV void node_step(const SceneView& sv, const LaneStack<StackT> stk, WorkCount* wc) {
+    // One interior-node visit: slab-test both children, descend into the nearer hit one, push the
+    // other.  The visit is ONE basic block with one LDS round trip: the top of the stack is fetched
+    // together with the node (it is the next node if neither child is hit), and the far child is
+    // stored above the top unconditionally; only the stack pointer moves conditionally.
+    template <bool COUNT>
+    PT_DEV void node_step(const SceneView& sv, WorkCount* wc) {
         const float kWiden = 1.0000005f;   // > 4 ulp: covers rcp + sub + mul rounding of the slab test
-        const float4 qx = sv.nodes[cur * 4 + 0];
-        const float4 qy = sv.nodes[cur * 4 + 1];
-        const float4 qz = sv.nodes[cur * 4 + 2];
-        const float4 qr = sv.nodes[cur * 4 + 3];
+        const int top = (int)*reinterpret_cast<const StackT*>(tos);
+        float ln, lf, rn, rf;
+        int li, ri;
         if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; }
-        const float lx0 = (qx.x - P.x) * inv.x, lx1 = (qx.y - P.x) * inv.x;
-        const float rx0 = (qx.z - P.x) * inv.x, rx1 = (qx.w - P.x) * inv.x;
-        const float ly0 = (qy.x - P.y) * inv.y, ly1 = (qy.y - P.y) * inv.y;
-        const float ry0 = (qy.z - P.y) * inv.y, ry1 = (qy.w - P.y) * inv.y;
-        const float lz0 = (qz.x - P.z) * inv.z, lz1 = (qz.y - P.z) * inv.z;
-        const float rz0 = (qz.z - P.z) * inv.z, rz1 = (qz.w - P.z) * inv.z;
-        const float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
-        const float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1)) * kWiden;
-        const float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
-        const float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1)) * kWiden;
+        if (kSel) {
+            // Swizzled quads {L.lo, R.lo, L.hi, R.hi}: the entry / exit planes of both children are
+            // picked by ADDRESS from the sign of the ray direction instead of by 12 v_min/v_max
+            // (4-cycle ops on gfx950, tools/micro/exec_ops.hip; the adds that form the addresses
+            // are 2-cycle ops).  A 0 * inf = NaN distance (origin on a plane, direction parallel to
+            // it) is ignored by max3/min3: that slab then counts as entered.
+            const char* nb = reinterpret_cast<const char*>(sv.nodes) + ((size_t)(unsigned)cur << 6);
+            const float2 ex = *reinterpret_cast<const float2*>(nb + onx), xx = *reinterpret_cast<const float2*>(nb + (onx ^ 8));
+            const float2 ey = *reinterpret_cast<const float2*>(nb + ony), xy = *reinterpret_cast<const float2*>(nb + (ony ^ 8));
+            const float2 ez = *reinterpret_cast<const float2*>(nb + onz), xz = *reinterpret_cast<const float2*>(nb + (onz ^ 8));
+            const int2 ch = *reinterpret_cast<const int2*>(nb + 48);
+            ln = fmaxf(fmaxf((ex.x - P.x) * inv.x, (ey.x - P.y) * inv.y), (ez.x - P.z) * inv.z);
+            rn = fmaxf(fmaxf((ex.y - P.x) * inv.x, (ey.y - P.y) * inv.y), (ez.y - P.z) * inv.z);
+            lf = fminf(fminf((xx.x - P.x) * inv.x, (xy.x - P.y) * inv.y), (xz.x - P.z) * inv.z) * kWiden;
+            rf = fminf(fminf((xx.y - P.x) * inv.x, (xy.y - P.y) * inv.y), (xz.y - P.z) * inv.z) * kWiden;
+            li = ch.x;
+            ri = ch.y;
+        } else {
+            const float4 qx = sv.nodes[cur * 4 + 0];
+            const float4 qy = sv.nodes[cur * 4 + 1];
+            const float4 qz = sv.nodes[cur * 4 + 2];
+            const float4 qr = sv.nodes[cur * 4 + 3];
+            // (plane - P) * inv keeps the relative error of each distance at ~2 ulp, which the 4-ulp
+            // widening covers.  Tried and rejected: the one-fma form plane*inv - P*inv (cancels; even
+            // with a per-ray error bound it culled a real hit in the parity suite, for +3 %).
+            const float lx0 = (qx.x - P.x) * inv.x, lx1 = (qx.y - P.x) * inv.x;
+            const float rx0 = (qx.z - P.x) * inv.x, rx1 = (qx.w - P.x) * inv.x;
+            const float ly0 = (qy.x - P.y) * inv.y, ly1 = (qy.y - P.y) * inv.y;
+            const float ry0 = (qy.z - P.y) * inv.y, ry1 = (qy.w - P.y) * inv.y;
+            const float lz0 = (qz.x - P.z) * inv.z, lz1 = (qz.y - P.z) * inv.z;
+            const float rz0 = (qz.z - P.z) * inv.z, rz1 = (qz.w - P.z) * inv.z;
+            ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
+            lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1)) * kWiden;
+            rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
+            rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1)) * kWiden;
+            li = __float_as_int(qr.x);
+            ri = __float_as_int(qr.y);
+        }
         const float lim = best_t * kWiden;
         const bool hl = (lf >= ln) && (lf >= 0.0f) && (ln <= lim);
         const bool hr = (rf >= rn) && (rf >= 0.0f) && (rn <= lim);
-        const int li = __float_as_int(qr.x), ri = __float_as_int(qr.y);
-        const bool lfirst = ln <= rn;
+        const bool lfirst = ln <= rn;      // (its own statement: inside the expression below it comes back as a branch)
         const bool take_left = hl && (!hr || lfirst);
-        int next = take_left ? li : ri;
-        if (hl && hr) {
-            stk.put(sp, take_left ? ri : li);
-            ++sp;
-        }
-        if (!(hl || hr)) {
-            next = kDone;
-            if (sp != 0) {
-                --sp;
-                next = stk.get(sp);
-            }
-        }
-        cur = next;
+        const bool both = hl && hr, none = !(hl || hr);
+        *reinterpret_cast<StackT*>(tos + stride) = (StackT)(take_left ? ri : li);
+        const int next = take_left ? li : ri;
+        cur = none ? top : next;
+        tos += both ? stride : (none ? -stride : 0);
     }
 
     // exact test of packed triangle ti against the ray, keeping the closest (ties: lower rank)
@@ -348,57 +376,60 @@ struct Trav {
         }
     }
 
-    template <class StackT>
-    PT_DEV void pop(const LaneStack<StackT> stk) {
-        if (sp == 0) {
-            cur = kDone;
-        } else {
-            --sp;
-            cur = stk.get(sp);
+    PT_DEV void pop() {
+        cur = (int)*reinterpret_cast<const StackT*>(tos);
+        tos -= stride;
+    }
+
+    template <bool COUNT>
+    PT_DEV void round(const SceneView& sv, WorkCount* wc) {
+        while (is_node(cur)) node_step<COUNT>(sv, wc);
+        while (is_leaf(cur)) {
+            const int popped = (int)*reinterpret_cast<const StackT*>(tos);     // in flight during the triangle tests
+            const int v = leaf_bits(cur);
+            const int first = v >> 3, count = (v & 7) + 1;
+            for (int j = 0; j < count; ++j) tri_step<COUNT>(sv, first + j, wc);
+            cur = popped;
+            tos -= stride;
         }
     }
 
-    template <class StackT, bool COUNT>
-    PT_DEV void round(const SceneView& sv, const LaneStack<StackT> stk, WorkCount* wc) {
-        while (cur >= 0 && cur != kDone) node_step<StackT, COUNT>(sv, stk, wc);
-        while (cur < 0) {
-            const int v = ~cur;
-            const int first = v >> 3, count = (v & 7) + 1;
-            for (int k = 0; k < count; ++k) tri_step<COUNT>(sv, first + k, wc);
-            pop(stk);
+    // one triangle of the current leaf (single-step schedules)
+    template <bool COUNT>
+    PT_DEV void leaf_step(const SceneView& sv, WorkCount* wc) {
+        const int v = leaf_bits(cur);
+        const int first = v >> 3, count = (v & 7) + 1;
+        tri_step<COUNT>(sv, first + k, wc);
+        if (++k >= count) {
+            k = 0;
+            pop();
         }
     }
 
     // Voting schedule: each step the wave runs ONE body -- a node visit or a single triangle test --
     // whichever more lanes are waiting for.  Lanes in the minority wait (and accumulate), so neither
     // body is ever executed for a thin tail of lanes as in the while-while loops.
-    template <class StackT, bool COUNT>
-    PT_DEV void vote_step(const SceneView& sv, const LaneStack<StackT> stk, WorkCount* wc) {
-        const bool want_node = cur >= 0 && cur != kDone;
-        const bool want_tri = cur < 0;
+    template <bool COUNT>
+    PT_DEV void vote_step(const SceneView& sv, WorkCount* wc) {
+        const bool want_node = is_node(cur);
+        const bool want_tri = is_leaf(cur);
         const int nn = __popcll(__ballot(want_node)), nt = __popcll(__ballot(want_tri));
         if (nn >= nt) {
-            if (want_node) node_step<StackT, COUNT>(sv, stk, wc);
+            if (want_node) node_step<COUNT>(sv, wc);
         } else if (want_tri) {
-            const int v = ~cur;
-            const int first = v >> 3, count = (v & 7) + 1;
-            tri_step<COUNT>(sv, first + k, wc);
-            if (++k >= count) {
-                k = 0;
-                pop(stk);
-            }
+            leaf_step<COUNT>(sv, wc);
         }
     }
 };
 
 template <class StackT, bool COUNT, bool VOTE>
 PT_DEV int closest_hit(const SceneView& sv, f3 P, f3 D, const LaneStack<StackT> stk, float* t_out, WorkCount* wc) {
-    Trav tr;
-    tr.begin(P, D);
+    Trav<StackT> tr;
+    tr.begin(P, D, stk);
     if (VOTE) {
-        while (__ballot(!tr.done()) != 0) tr.template vote_step<StackT, COUNT>(sv, stk, wc);
+        while (__ballot(!tr.done()) != 0) tr.template vote_step<COUNT>(sv, wc);
     } else {
-        while (!tr.done()) tr.template round<StackT, COUNT>(sv, stk, wc);
+        while (!tr.done()) tr.template round<COUNT>(sv, wc);
     }
     *t_out = tr.best_t;
     return tr.best;
@@ -545,9 +576,26 @@ PT_DEV f3 running_mean(f3 acc, f3 color, int s) {   // prog.cl:379
 // ---------------------------------------------------------------------------- LDS staging
 extern __shared__ __attribute__((aligned(16))) unsigned char pt_lds_raw[];
 
+// Nodes staged in LDS are re-laid out on the way in: the three box quads {L.lo, L.hi, R.lo, R.hi}
+// become {L.lo, R.lo, L.hi, R.hi}, so that one 8-byte read at (quad + 0 | 8) returns the entry
+// (or exit) planes of BOTH children for a ray whose direction sign on that axis is known
+// (Trav::node_step, kSel).  The child slots of the fourth quad are re-encoded to the 16-bit
+// reference form of Trav<unsigned short>.
+PT_DEV float stage_ref(float slot) {
+    const int r = __float_as_int(slot);
+    return __int_as_float(r < 0 ? (0x8000 | ~r) : r);
+}
+PT_DEV void stage_nodes(const RenderParams& p, float4* lds_nodes) {
+    const int nn = p.n_nodes * 4;
+    for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+        const float4 q = p.nodes[i];
+        lds_nodes[i] = (i & 3) == 3 ? make_float4(stage_ref(q.x), stage_ref(q.y), q.z, q.w) : make_float4(q.x, q.z, q.y, q.w);
+    }
+}
+
 PT_DEV void stage_scene(const RenderParams& p, float4* lds_nodes, float4* lds_tris) {
-    const int nn = p.n_nodes * 4, nt = p.n_tris * 3;
-    for (int i = threadIdx.x; i < nn; i += blockDim.x) lds_nodes[i] = p.nodes[i];
+    const int nt = p.n_tris * 3;
+    stage_nodes(p, lds_nodes);
     for (int i = threadIdx.x; i < nt; i += blockDim.x) lds_tris[i] = p.tris[i];
     __syncthreads();
 }
@@ -679,7 +727,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render(RenderParams p) {
             stage_scene(p, lds_nodes, lds_tris);
             sv.tris = lds_tris;
         } else {
-            for (int i = threadIdx.x; i < p.n_nodes * 4; i += BLOCK) lds_nodes[i] = p.nodes[i];
+            stage_nodes(p, lds_nodes);
             __syncthreads();
         }
         sv.nodes = lds_nodes;
@@ -776,9 +824,9 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render_sliced(RenderParams p, i
         const int s_end = p.first_sample + p.nsamples;
         int bounce = 0;
         bool fresh = true, traversing = false;
-        Trav tr;
-        tr.begin(rP, rD);
-        tr.cur = Trav::kDone;
+        Trav<unsigned> tr;
+        tr.begin(rP, rD, stk);
+        tr.idle();
         for (;;) {
             if (!traversing) {
                 if (fresh) {
@@ -796,16 +844,16 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_render_sliced(RenderParams p, i
                 }
                 traversing = true;
                 if (bounce < p.iterations) {
-                    tr.begin(rP, rD);
+                    tr.begin(rP, rD, stk);
                     ++segs;
                 } else {                        // iterations == 0: nothing to trace
-                    tr.cur = Trav::kDone;
+                    tr.idle();
                     tr.best = -1;
                 }
             }
             for (int r = 0; r < slice; ++r) {
                 if (__ballot(!tr.done()) == 0) break;
-                if (!tr.done()) tr.template round<unsigned, false>(sv, stk, &wc);
+                if (!tr.done()) tr.template round<false>(sv, &wc);
             }
             if (tr.done()) {
                 traversing = false;
@@ -986,9 +1034,9 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
     unsigned cbase = block_base + wave * kWfRaysPerWave;  // uniform per wave: next unassigned ray
     const unsigned cend = min(cbase + (unsigned)kWfRaysPerWave, n);
     if (cbase > cend) cbase = cend;
-    Trav tr;
-    tr.begin(mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f));
-    tr.cur = Trav::kDone;
+    Trav<unsigned> tr;
+    tr.begin(mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), stk);
+    tr.idle();
     unsigned pos = ~0u;          // stream position of the ray in flight (~0u: none)
     unsigned npos = ~0u;         // prefetched next ray (~0u: none)
     float4 nA = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -999,7 +1047,7 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
         if (tr.done() && npos != ~0u) {
             pos = npos;
             npos = ~0u;
-            tr.begin(mk(nA.x, nA.y, nA.z), mk(nA.w, nB.x, nB.y));
+            tr.begin(mk(nA.x, nA.y, nA.z), mk(nA.w, nB.x, nB.y), stk);
         }
         // ---- lanes without a prefetched ray reserve the next positions of the wave's range
         const unsigned long long want = __ballot(npos == ~0u);
@@ -1014,16 +1062,8 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
         }
         if (__ballot(!tr.done() || npos != ~0u) == 0) break;
         // ---- one node visit, then one triangle test
-        if (tr.cur >= 0 && tr.cur != Trav::kDone) tr.template node_step<unsigned, false>(sv, stk, &wc);
-        if (tr.cur < 0) {
-            const int v = ~tr.cur;
-            const int first = v >> 3, count = (v & 7) + 1;
-            tr.template tri_step<false>(sv, first + tr.k, &wc);
-            if (++tr.k >= count) {
-                tr.k = 0;
-                tr.pop(stk);
-            }
-        }
+        if (tr.is_node(tr.cur)) tr.template node_step<false>(sv, &wc);
+        if (tr.is_leaf(tr.cur)) tr.template leaf_step<false>(sv, &wc);
         // ---- finished: hit record + class byte
         if (tr.done() && pos != ~0u) {
             hits[pos] = make_float2(tr.best_t, __int_as_float(tr.best));
@@ -1204,7 +1244,7 @@ static inline int n_waves(const RenderParams& p) {
 
 int mega_max_lds_scene_bytes() { return 160 * 1024; }
 
-static inline bool stack16_ok(const RenderParams& p) { return p.lds_scene && p.n_nodes <= 32768 && p.n_tris <= 4096; }
+static inline bool stack16_ok(const RenderParams& p) { return p.lds_scene && p.n_nodes <= 32767 && p.n_tris <= 4096; }
 
 size_t mega_lds_bytes(const RenderParams& p, int block) {
     size_t b = (size_t)p.stack_entries * (stack16_ok(p) ? 2 : 4) * (size_t)block;
@@ -1318,8 +1358,9 @@ hipError_t launch_wf_shade(const WfParams& w, int bounce, hipStream_t stream) {
 // global); 512-thread blocks, 16-bit stack entries, grid-stride over the rays
 template <bool LDS_NODES>
 __global__ void __launch_bounds__(512) k_debug_closest_hit_persist(RenderParams p, const pt_ray* rays, long long n, float* out_t, int* out_tri) {
-    LaneStack<unsigned short> stk;
-    stk.base = reinterpret_cast<unsigned short*>(pt_lds_raw) + threadIdx.x;
+    using StackT = typename std::conditional<LDS_NODES, unsigned short, unsigned>::type;   // 16-bit refs only with staged nodes
+    LaneStack<StackT> stk;
+    stk.base = reinterpret_cast<StackT*>(pt_lds_raw) + threadIdx.x;
     stk.stride = 512;
     SceneView sv;
     sv.nodes = p.nodes;
@@ -1327,7 +1368,7 @@ __global__ void __launch_bounds__(512) k_debug_closest_hit_persist(RenderParams 
     sv.meta = p.meta;
     if (LDS_NODES) {
         float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + (((size_t)p.stack_entries * 2 * 512 + 15) & ~(size_t)15));
-        for (int i = threadIdx.x; i < p.n_nodes * 4; i += 512) lds_nodes[i] = p.nodes[i];
+        stage_nodes(p, lds_nodes);
         __syncthreads();
         sv.nodes = lds_nodes;
     }
@@ -1336,7 +1377,7 @@ __global__ void __launch_bounds__(512) k_debug_closest_hit_persist(RenderParams 
         const float4* r = reinterpret_cast<const float4*>(&rays[i]);
         const float4 a = r[0], b = r[1];
         float t;
-        const int ti = closest_hit<unsigned short, false, false>(sv, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), stk, &t, &wc);
+        const int ti = closest_hit<StackT, false, false>(sv, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), stk, &t, &wc);
         out_t[i] = ti >= 0 ? t : -1.0f;
         out_tri[i] = ti;
     }
@@ -1346,8 +1387,8 @@ hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, i
     if (n == 0) return hipSuccess;
     if (lds_pad == 1 || lds_pad == 2) {      // 1: persistent, nodes from global; 2: persistent, nodes in LDS
         const bool in_lds = lds_pad == 2;
-        size_t lds = (((size_t)p.stack_entries * 2 * 512 + 15) & ~(size_t)15) + (in_lds ? (size_t)p.n_nodes * 64 : 0);
-        if (p.n_nodes > 32768 || p.n_tris > 4096 || lds > 80 * 1024) return hipErrorInvalidValue;
+        size_t lds = (((size_t)p.stack_entries * (in_lds ? 2 : 4) * 512 + 15) & ~(size_t)15) + (in_lds ? (size_t)p.n_nodes * 64 : 0);
+        if (p.n_nodes > 32767 || p.n_tris > 4096 || lds > 80 * 1024) return hipErrorInvalidValue;
         auto kern = in_lds ? k_debug_closest_hit_persist<true> : k_debug_closest_hit_persist<false>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -7,7 +7,7 @@
 #define CHAIN8(OPSTR)                                                                                         \
     asm volatile(OPSTR(0) OPSTR(1) OPSTR(2) OPSTR(3) OPSTR(4) OPSTR(5) OPSTR(6) OPSTR(7)                      \
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)              \
-                 : "v"(m), "v"(c) : "vcc")
+                 : "v"(m), "v"(c) : "vcc", "s10", "s11", "s12", "v20", "v21", "v22", "v23", "v24", "v25")
 
 #define OP_FMA(i)  "v_fma_f32 %" #i ", %" #i ", %8, %9\n"
 #define OP_MUL(i)  "v_mul_f32 %" #i ", %" #i ", %8\n"
@@ -23,6 +23,26 @@
 #define OP_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %9\n"
 #define OP_SUB(i)  "v_sub_f32 %" #i ", %" #i ", %9\n"
 #define OP_MIN3(i) "v_min3_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_CNDS(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %9, s[10:11]\n"
+#define OP_LSHLADD(i) "v_lshl_add_u32 %" #i ", %" #i ", 6, %9\n"
+#define OP_ADD3(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
+#define OP_MAD24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
+#define OP_CMPS(i) "v_cmp_le_f32_e64 s[10:11], %" #i ", %9\n"
+#define OP_MED3(i) "v_med3_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_XOR(i)  "v_xor_b32 %" #i ", %" #i ", %9\n"
+#define OP_FMAC(i) "v_fmac_f32 %" #i ", %8, %9\n"
+#define OP_FMAS(i) "v_fma_f32 %" #i ", %" #i ", s12, %9\n"
+#define OP_MULL(i) "v_mul_f32 %" #i ", 0x3f800004, %" #i "\n"
+#define OP_MIN(i)  "v_min_f32 %" #i ", %" #i ", %9\n"
+#define OP_SUBU(i) "v_sub_u32 %" #i ", %" #i ", %9\n"
+#define OP_LSHR(i) "v_lshrrev_b32 %" #i ", 3, %" #i "\n"
+#define OP_PKFMA(i) "v_pk_fma_f32 v[20:21], v[20:21], v[22:23], v[24:25]\n"
+#define OP_PKMUL(i) "v_pk_mul_f32 v[20:21], v[20:21], v[22:23]\n"
+#define OP_FMA64(i) "v_fma_f64 v[20:21], v[20:21], v[22:23], v[24:25]\n"
+#define OP_MUL64(i) "v_mul_f64 v[20:21], v[20:21], v[22:23]\n"
+#define OP_SQRT(i) "v_sqrt_f32 %" #i ", %" #i "\n"
+#define OP_BITOP(i) "v_bitop3_b32 %" #i ", %" #i ", %8, %9 bitop3:0xcf\n"
+#define OP_CVT(i) "v_cvt_f32_i32 %" #i ", %" #i "\n"
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(unsigned long long mask, int iters, float* out) {
@@ -47,6 +67,26 @@ __global__ void __launch_bounds__(256) k(unsigned long long mask, int iters, flo
                 if (OP == 11) CHAIN8(OP_MULLO);
                 if (OP == 12) CHAIN8(OP_SUB);
                 if (OP == 13) CHAIN8(OP_MIN3);
+                if (OP == 14) CHAIN8(OP_CNDS);
+                if (OP == 15) CHAIN8(OP_LSHLADD);
+                if (OP == 16) CHAIN8(OP_ADD3);
+                if (OP == 17) CHAIN8(OP_MAD24);
+                if (OP == 18) CHAIN8(OP_CMPS);
+                if (OP == 19) CHAIN8(OP_MED3);
+                if (OP == 20) CHAIN8(OP_XOR);
+                if (OP == 21) CHAIN8(OP_FMAC);
+                if (OP == 22) CHAIN8(OP_FMAS);
+                if (OP == 23) CHAIN8(OP_MULL);
+                if (OP == 24) CHAIN8(OP_MIN);
+                if (OP == 25) CHAIN8(OP_SUBU);
+                if (OP == 26) CHAIN8(OP_LSHR);
+                if (OP == 27) CHAIN8(OP_PKFMA);
+                if (OP == 28) CHAIN8(OP_PKMUL);
+                if (OP == 29) CHAIN8(OP_FMA64);
+                if (OP == 30) CHAIN8(OP_MUL64);
+                if (OP == 31) CHAIN8(OP_SQRT);
+                if (OP == 32) CHAIN8(OP_BITOP);
+                if (OP == 33) CHAIN8(OP_CVT);
             }
         }
     }
@@ -81,5 +121,9 @@ int main() {
     run<0>("v_fma_f32", o); run<1>("v_mul_f32", o); run<2>("v_add_f32", o); run<12>("v_sub_f32", o); run<3>("v_max_f32", o);
     run<13>("v_min3_f32", o); run<4>("v_cmp_lt_f32", o); run<5>("v_cndmask_b32", o); run<6>("v_mov_b32", o); run<7>("v_add_u32", o);
     run<8>("v_and_b32", o); run<9>("v_lshlrev_b32", o); run<10>("v_rcp_f32", o); run<11>("v_mul_lo_u32", o);
+    run<14>("cndmask sgpr", o); run<15>("v_lshl_add_u32", o); run<16>("v_add3_u32", o); run<17>("v_mad_u32_u24", o); run<18>("v_cmp e64 sgpr", o);
+    run<19>("v_med3_f32", o); run<20>("v_xor_b32", o); run<21>("v_fmac_f32", o); run<22>("v_fma sgpr op", o); run<23>("v_mul literal", o);
+    run<24>("v_min_f32", o); run<25>("v_sub_u32", o); run<26>("v_lshrrev_b32", o); run<27>("v_pk_fma_f32", o); run<28>("v_pk_mul_f32", o);
+    run<29>("v_fma_f64", o); run<30>("v_mul_f64", o); run<31>("v_sqrt_f32", o); run<32>("v_bitop3_b32", o); run<33>("v_cvt_f32_i32", o);
     return 0;
 }

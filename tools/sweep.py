@@ -37,12 +37,22 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
         W, H, bounces, spp, str(opts), sc.stat("bvh_nodes"), sc.stat("lds_bytes"), samples / dt / 1e6, samples / kms / 1e3, segs / samples, segs / kms / 1e3, extra), flush=True)
 
 
+def checksum(W, H, bounces, spp, spec, **opts):
+    import numpy as np
+    sc = api.Scene(W, H)
+    sc.load(spec)
+    for k, v in opts.items():
+        sc.set_option(k, v)
+    sc.iterations = bounces
+    sc.render(spp)
+    sc.sync()
+    return float(np.asarray(sc.read_colors(), dtype=np.float64).sum()), int(np.asarray(sc.read_rnds(), dtype=np.int64).sum())
+
+
 if __name__ == "__main__":
     W, H = 1920, 1080
-    for n, b in ((100000, 8), (1000000, 16)):
-        spec = scenes.displaced_grid_mesh(n)
-        run(W, H, b, 16, spec, reps=2)
-        run(W, H, b, 16, spec, reps=2, variant=1)
     spec = scenes.cornell_box()
-    run(3840, 2160, 8, 16, spec, reps=2)
-    run(256, 256, 4, 16, spec, reps=4)
+    print("checksum lds nodes  ", checksum(512, 512, 8, 4, spec))
+    print("checksum global path", checksum(512, 512, 8, 4, spec, lds_scene=0), flush=True)
+    run(W, H, 8, 64, spec, reps=3)
+    run(W, H, 8, 64, spec, reps=2, lds_scene=0)
