@@ -138,10 +138,24 @@ PT_DEV float spec_pow(float x, float y) {
     return (float)(q * sc);
 }
 
-// ---- LCG, prog.cl:72-77
+// ---- LCG, prog.cl:72-77: n = (ulong)seed * 48271 % 2147483647.
+// For seed >= 0 the product is < 2^47 and the modulus is the Mersenne number 2^31 - 1:
+// n = hi * 2^31 + lo = hi + lo (mod M) with hi < 2^16, so one conditional subtraction finishes it
+// (8 32-bit instructions instead of the ~30 of a 64-bit multiply and remainder).  A negative seed
+// (only possible for a seed the caller uploaded; every output is in [0, M)) sign-extends to 64 bits
+// as in the reference and takes the generic path.
 PT_DEV float lcg_rand(int& seed) {
-    unsigned long long n = (unsigned long long)(long long)seed;
-    n = (n * 48271ull) % 2147483647ull;
+    unsigned n;
+    if (seed >= 0) {
+        const unsigned s = (unsigned)seed;
+        const unsigned plo = s * 48271u, phi = __umulhi(s, 48271u);
+        const unsigned t = (plo & 0x7fffffffu) + ((phi << 1) | (plo >> 31));
+        n = min(t, t - 2147483647u);
+    } else {
+        unsigned long long w = (unsigned long long)(long long)seed;
+        w = (w * 48271ull) % 2147483647ull;
+        n = (unsigned)w;
+    }
     seed = (int)n;
     return (float)n / 2147483648.0f;
 }
