@@ -1240,7 +1240,11 @@ int pt_debug_closest_hit(pt_context* ctx, const pt_ray* rays, int64_t n, float* 
     PT_HIP(ctx, hipMalloc((void**)&d_t, sizeof(float) * nn));
     PT_HIP(ctx, hipMalloc((void**)&d_tri, sizeof(int32_t) * nn));
     PT_HIP(ctx, hipMemcpy(d_rays, rays, sizeof(pt_ray) * (size_t)n, hipMemcpyHostToDevice));
-    PT_HIP(ctx, launch_debug_closest_hit(p, d_rays, n, d_t, d_tri, ctx->stream));
+    // same node path as the render kernel would take: nodes staged in LDS (swizzled quads, 16-bit
+    // references, one-fma slab test) when the scene qualifies, otherwise straight from global memory
+    int blk = 0;
+    decide_lds_scene(ctx, &p, &blk);
+    PT_HIP(ctx, launch_debug_closest_hit(p, d_rays, n, d_t, d_tri, ctx->stream, p.lds_scene == 2 ? 2 : 0));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->debug_repeat > 0) {      // traversal-only timing: the same launch, debug_repeat times
         hipEvent_t e0, e1;

@@ -293,6 +293,7 @@ struct Trav {
     int cur;
     int k;         // single-step schedules: next triangle of the current leaf
     int onx, ony, onz;   // kSel: byte offset of the entry-plane pair of each axis inside a node
+    f3 cn, cf;           // kSel: -(P * inv) widened down / up (entry / exit distance = fma(plane, inv, c))
 
     PT_DEV static bool is_node(int c) { return kSel ? c < 0x7fff : (unsigned)c < 0x7fffffffu; }
     PT_DEV static bool is_leaf(int c) { return kSel ? c > 0x7fff : c < 0; }
@@ -312,6 +313,19 @@ struct Trav {
         onx = __float_as_int(inv.x) < 0 ? 8 : 0;
         ony = __float_as_int(inv.y) < 0 ? 24 : 16;
         onz = __float_as_int(inv.z) < 0 ? 40 : 32;
+        if (kSel) {
+            // distance to a plane as ONE fma: plane * inv - P * inv.  The product P * inv is rounded
+            // (half an ulp of |P * inv|, which can dwarf the distance itself), so the entry constant
+            // is lowered and the exit constant raised by 4 such half-ulps: entry distances come out
+            // too small, exit distances too large, never the other way round.  inf - inf = NaN
+            // (direction component 0 or underflowing) is ignored by max3/min3: that slab counts as
+            // entered, which only costs work.
+            const float px = P.x * inv.x, py = P.y * inv.y, pz = P.z * inv.z;
+            const float k = 2.3841858e-07f;    // 2^-22
+            const float ex = __builtin_fabsf(px) * k, ey = __builtin_fabsf(py) * k, ez = __builtin_fabsf(pz) * k;
+            cn = mk(-(px + ex), -(py + ey), -(pz + ez));
+            cf = mk(-(px - ex), -(py - ey), -(pz - ez));
+        }
     }
     PT_DEV void idle() { cur = kDone; }
     PT_DEV bool done() const { return cur == kDone; }
@@ -338,10 +352,10 @@ struct Trav {
             const float2 ey = *reinterpret_cast<const float2*>(nb + ony), xy = *reinterpret_cast<const float2*>(nb + (ony ^ 8));
             const float2 ez = *reinterpret_cast<const float2*>(nb + onz), xz = *reinterpret_cast<const float2*>(nb + (onz ^ 8));
             const int2 ch = *reinterpret_cast<const int2*>(nb + 48);
-            ln = fmaxf(fmaxf((ex.x - P.x) * inv.x, (ey.x - P.y) * inv.y), (ez.x - P.z) * inv.z);
-            rn = fmaxf(fmaxf((ex.y - P.x) * inv.x, (ey.y - P.y) * inv.y), (ez.y - P.z) * inv.z);
-            lf = fminf(fminf((xx.x - P.x) * inv.x, (xy.x - P.y) * inv.y), (xz.x - P.z) * inv.z) * kWiden;
-            rf = fminf(fminf((xx.y - P.x) * inv.x, (xy.y - P.y) * inv.y), (xz.y - P.z) * inv.z) * kWiden;
+            ln = fmaxf(fmaxf(fmaf_(ex.x, inv.x, cn.x), fmaf_(ey.x, inv.y, cn.y)), fmaf_(ez.x, inv.z, cn.z));
+            rn = fmaxf(fmaxf(fmaf_(ex.y, inv.x, cn.x), fmaf_(ey.y, inv.y, cn.y)), fmaf_(ez.y, inv.z, cn.z));
+            lf = fminf(fminf(fmaf_(xx.x, inv.x, cf.x), fmaf_(xy.x, inv.y, cf.y)), fmaf_(xz.x, inv.z, cf.z)) * kWiden;
+            rf = fminf(fminf(fmaf_(xx.y, inv.x, cf.x), fmaf_(xy.y, inv.y, cf.y)), fmaf_(xz.y, inv.z, cf.z)) * kWiden;
             li = ch.x;
             ri = ch.y;
         } else {

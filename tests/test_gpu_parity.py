@@ -460,6 +460,51 @@ def test_closest_hit_unit_level(api, oracle, cb_spec, cb_oracle_scene):
     assert np.array_equal(tris_add_order["mati"][tri[hitmask]], h2["mati"][hitmask])
 
 
+@pytest.mark.parametrize("lds_scene", [2, 0])
+def test_closest_hit_adversarial_rays(api, oracle, cb_spec, cb_oracle_scene, lds_scene):
+    """Rays chosen against the conservative slab tests of both node paths (nodes staged in LDS:
+    address-selected planes + one fma per plane with widened constants; nodes from global memory:
+    (plane - P) * inv): origins 1e4..1e7 away from the scene (|P * inv| >> t, where the fma form
+    cancels), direction components that are tiny, denormal or exactly +-0, origins exactly on the
+    wall planes and sliding along them, origins inside the spheres.  The device result must be
+    bit-identical to the oracle's exhaustive search on every ray."""
+    rng = np.random.RandomState(17)
+    n = 24000
+    tgt = np.stack([rng.uniform(0, 1000, n), rng.uniform(0, 1000, n), rng.uniform(-1000, 1000, n)], 1)
+    D = rng.normal(size=(n, 3))
+    D /= np.linalg.norm(D, axis=1)[:, None]
+    dist = np.ones(n)
+    dist[:6000] = 10.0 ** rng.uniform(4, 7, 6000)             # far origins aimed at the scene
+    P = tgt - D * dist[:, None] * np.where(np.arange(n) < 6000, 1.0, rng.uniform(0, 600, n))[:, None]
+    P = P.astype(np.float32)
+    D = D.astype(np.float32)
+    for k, val in enumerate([1e-12, 1e-25, 1e-38, 1e-42, 0.0, -0.0]):       # tiny / denormal / zero components
+        sl = slice(6000 + 1500 * k, 6000 + 1500 * (k + 1))
+        axis = rng.randint(0, 3, 1500)
+        sign = rng.choice([-1.0, 1.0], 1500)
+        D[sl][np.arange(1500), axis] = (sign * val).astype(np.float32)
+    on = slice(15000, 18000)                                   # origins exactly on a wall plane, direction inside it
+    axis = rng.randint(0, 3, 3000)
+    plane = np.where(rng.rand(3000) < 0.5, 0.0, 1000.0)
+    plane = np.where(axis == 2, np.where(rng.rand(3000) < 0.5, -1000.0, 1000.0), plane)
+    P[on][np.arange(3000), axis] = plane.astype(np.float32)
+    D[on][np.arange(3000), axis] = 0.0
+    inside = slice(18000, 21000)                               # origins inside the two spheres
+    cen = np.concatenate([cb_spec.objects[1][0].reshape(-1, 3).mean(0)[None], cb_spec.objects[2][0].reshape(-1, 3).mean(0)[None]])
+    P[inside] = (cen[rng.randint(0, 2, 3000)] + rng.normal(size=(3000, 3)) * 40).astype(np.float32)
+    rays = np.zeros(n, dtype=api.RAY)
+    rays["P"][:, :3] = P
+    rays["D"][:, :3] = D
+    sc = api.Scene(16, 16)
+    sc.set_option("lds_scene", lds_scene)
+    sc.load(cb_spec)
+    t, tri = sc.debug_closest_hit(rays)
+    h2 = cb_oracle_scene.closest_hit(rays.view(oracle.RAY), mode=2)
+    ot2 = np.where(h2["t"] > 0, h2["t"], np.float32(-1))
+    assert same_bits(t, ot2)
+    assert (t > 0).sum() > 15000
+
+
 @pytest.mark.parametrize("which,ntris", [("cornell", 0), ("mesh", 6000), ("mesh", 100000)])
 def test_device_bvh_builder(api, oracle, cb_spec, cb_oracle_scene, which, ntris):
     """bvh_policy 4: the tree is built ON THE DEVICE (LBVH: Morton codes, radix sort, Karras,
