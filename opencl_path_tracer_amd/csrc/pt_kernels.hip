@@ -314,7 +314,7 @@ struct Trav {
         ony = __float_as_int(inv.y) < 0 ? 24 : 16;
         onz = __float_as_int(inv.z) < 0 ? 40 : 32;
         if (kSel) {
-            // distance to a plane as ONE fma: plane * inv - P * inv.  The product P * inv is rounded
+            // Distance to a plane as ONE fma: plane * inv - P * inv.  The product P * inv is rounded
             // (half an ulp of |P * inv|, which can dwarf the distance itself), so the entry constant
             // is lowered and the exit constant raised by 4 such half-ulps: entry distances come out
             // too small, exit distances too large, never the other way round.  inf - inf = NaN
@@ -336,7 +336,7 @@ struct Trav {
     // stored above the top unconditionally; only the stack pointer moves conditionally.
     template <bool COUNT>
     PT_DEV void node_step(const SceneView& sv, WorkCount* wc) {
-        const float kWiden = 1.0000005f;   // > 4 ulp: covers rcp + sub + mul rounding of the slab test
+        const float kWiden = 1.0000005f;   // > 4 ulp: covers rcp + sub + mul (or the fma; begin() covers P * inv)
         const int top = (int)*reinterpret_cast<const StackT*>(tos);
         float ln, lf, rn, rf;
         int li, ri;
@@ -345,8 +345,7 @@ struct Trav {
             // Swizzled quads {L.lo, R.lo, L.hi, R.hi}: the entry / exit planes of both children are
             // picked by ADDRESS from the sign of the ray direction instead of by 12 v_min/v_max
             // (4-cycle ops on gfx950, tools/micro/exec_ops.hip; the adds that form the addresses
-            // are 2-cycle ops).  A 0 * inf = NaN distance (origin on a plane, direction parallel to
-            // it) is ignored by max3/min3: that slab then counts as entered.
+            // are 2-cycle ops).
             const char* nb = reinterpret_cast<const char*>(sv.nodes) + ((size_t)(unsigned)cur << 6);
             const float2 ex = *reinterpret_cast<const float2*>(nb + onx), xx = *reinterpret_cast<const float2*>(nb + (onx ^ 8));
             const float2 ey = *reinterpret_cast<const float2*>(nb + ony), xy = *reinterpret_cast<const float2*>(nb + (ony ^ 8));
@@ -363,9 +362,10 @@ struct Trav {
             const float4 qy = sv.nodes[cur * 4 + 1];
             const float4 qz = sv.nodes[cur * 4 + 2];
             const float4 qr = sv.nodes[cur * 4 + 3];
-            // (plane - P) * inv keeps the relative error of each distance at ~2 ulp, which the 4-ulp
-            // widening covers.  Tried and rejected: the one-fma form plane*inv - P*inv (cancels; even
-            // with a per-ray error bound it culled a real hit in the parity suite, for +3 %).
+            // (plane - P) * inv: ~2 ulp per distance, covered by the 4-ulp widening.  The one-fma form
+            // is NOT used here: with min/max picking the planes, a NaN from inf - inf (direction
+            // component 0 or underflowing) would be replaced by the OTHER plane's distance and cull
+            // real hits (tests/test_gpu_parity.py::test_closest_hit_adversarial_rays).
             const float lx0 = (qx.x - P.x) * inv.x, lx1 = (qx.y - P.x) * inv.x;
             const float rx0 = (qx.z - P.x) * inv.x, rx1 = (qx.w - P.x) * inv.x;
             const float ly0 = (qy.x - P.y) * inv.y, ly1 = (qy.y - P.y) * inv.y;

@@ -54,5 +54,6 @@ if __name__ == "__main__":
     spec = scenes.cornell_box()
     print("checksum lds nodes  ", checksum(512, 512, 8, 4, spec))
     print("checksum global path", checksum(512, 512, 8, 4, spec, lds_scene=0), flush=True)
-    run(W, H, 8, 64, spec, reps=3)
+    run(W, H, 8, 64, spec, reps=2)
     run(W, H, 8, 64, spec, reps=2, lds_scene=0)
+    run(W, H, 8, 16, scenes.displaced_grid_mesh(100000), reps=2)
