@@ -7,7 +7,7 @@ sys.path.insert(0, ".")
 from opencl_path_tracer_amd import api, scenes  # noqa: E402
 
 spec = scenes.cornell_box()
-W, H, B, SPP, STEPS = 1920, 1080, 8, 16, 16
+W, H, B, SPP, STEPS = 1920, 1080, 8, 64, 4
 
 
 def t_rank(world, rank, rb=8, **opts):

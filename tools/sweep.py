@@ -50,10 +50,12 @@ def checksum(W, H, bounces, spp, spec, **opts):
 
 
 if __name__ == "__main__":
-    W, H = 1920, 1080
-    spec = scenes.cornell_box()
-    print("checksum lds nodes  ", checksum(512, 512, 8, 4, spec))
-    print("checksum global path", checksum(512, 512, 8, 4, spec, lds_scene=0), flush=True)
-    run(W, H, 8, 64, spec, reps=2)
-    run(W, H, 8, 64, spec, reps=2, lds_scene=0)
-    run(W, H, 8, 16, scenes.displaced_grid_mesh(100000), reps=2)
+    cb = scenes.cornell_box()
+    run(256, 256, 4, 64, cb, reps=4)
+    m100 = scenes.displaced_grid_mesh(100000)
+    run(1920, 1080, 8, 16, m100, reps=2)
+    run(1920, 1080, 8, 16, m100, reps=2, variant=1)
+    run(3840, 2160, 8, 16, cb, reps=2)
+    m1m = scenes.displaced_grid_mesh(1000000)
+    run(1920, 1080, 16, 8, m1m, reps=2)
+    run(1920, 1080, 16, 8, m1m, reps=2, variant=1)
