@@ -94,6 +94,7 @@ struct pt_context {
     uint32_t* d_tile_done = nullptr;
     int chunk_spp = -1;   // persistent megakernel work items: > 0 (pass, tile) items of that many samples, 0 whole
                           // tiles, -1 automatic (4 when the context has clearly more tiles than resident waves)
+    int sah_visit_cost = 10;   // tenths of a triangle test (option sah_visit_cost)
     int pixel_map = 0;    // 0 tiles of 8x8 per wave, 1 strided (balances waves; for ranks with few waves)
     int debug_lds_pad = 0; // extra LDS bytes per block of the timed debug launches (limits occupancy)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
@@ -230,6 +231,7 @@ struct BvhBuilder {
     int max_depth_seen = 0;
     int max_leaf = kMaxLeaf;     // leaf size limit of this attempt
     bool force_leaf = false;     // true: every subtree of <= max_leaf triangles becomes a leaf
+    float visit_cost = 1.0f;     // SAH price of one node visit, in exact triangle tests
 
     static int need_levels(size_t n) {  // levels a median-split subtree of n prims needs
         size_t leaves = (n + 3) / 4;
@@ -290,7 +292,7 @@ struct BvhBuilder {
         }
         // SAH termination: a node visit (64 B, two slab tests) is priced like one exact triangle test
         const float leaf_cost = b.half_area() * (float)n;
-        if (n <= (size_t)max_leaf && (force_leaf || !(best_cost + b.half_area() < leaf_cost))) return make_leaf(lo, hi);
+        if (n <= (size_t)max_leaf && (force_leaf || !(best_cost + visit_cost * b.half_area() < leaf_cost))) return make_leaf(lo, hi);
 
         size_t mid = lo;
         bool median = (best_axis < 0);
@@ -351,6 +353,7 @@ int build_attempt(pt_context* ctx, BvhBuilder& bld, const std::vector<BuildPrim>
     bld.prims = prims;
     bld.max_leaf = max_leaf;
     bld.force_leaf = force_leaf;
+    bld.visit_cost = (float)ctx->sah_visit_cost * 0.1f;
     bld.nodes.reserve(prims.size());
     bld.order.reserve(prims.size());
     // The root must be an interior node: wrap a leaf / an empty scene.
@@ -1143,6 +1146,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         ctx->chunk_spp = (int)value;
     } else if (k == "persistent") {
         ctx->persistent = value ? 1 : 0;
+    } else if (k == "sah_visit_cost") {
+        if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "sah_visit_cost: tenths of a triangle test, 0..1000");
+        ctx->sah_visit_cost = (int)value;
     } else if (k == "pixel_map") {
         ctx->pixel_map = value ? 1 : 0;
     } else if (k == "debug_lds_pad") {
