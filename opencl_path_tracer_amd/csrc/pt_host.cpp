@@ -998,9 +998,12 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         p.tile_counter = ctx->d_tile_counter;
         // automatic: chaining passes only pays when there are enough tiles to re-balance; with about one
         // tile per resident wave (a 1080p frame over 8 GPUs) the most expensive tile is the critical path
-        // either way and the extra hand-offs cost 2-4 %
+        // either way and the extra hand-offs cost 2-4 %.  With many tiles per wave (one GPU, 1080p: 7.9)
+        // passes of 8 samples re-balance just as well as passes of 4 and halve the hand-overs
+        // (measured 0 / 2 / 4 / 8 / 16 -> 1409 / 1406 / 1456 / 1470 / 1465 Msamples/s).
         const int resident_waves = ctx->cu_count * 16;
-        const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : (p.n_tiles > resident_waves + resident_waves / 2 ? 4 : 0);
+        const int auto_chunk = p.n_tiles >= 6 * resident_waves ? 8 : (p.n_tiles > resident_waves + resident_waves / 2 ? 4 : 0);
+        const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk;
         if (chunk > 0 && nsamples > chunk && p.n_tiles > 0) {
             if (!ctx->d_tile_done) PT_HIP(ctx, hipMalloc((void**)&ctx->d_tile_done, sizeof(uint32_t) * (size_t)p.n_tiles));
             PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_done, 0, sizeof(uint32_t) * (size_t)p.n_tiles, ctx->stream));
