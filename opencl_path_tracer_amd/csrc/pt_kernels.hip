@@ -6,17 +6,20 @@
 // samples, prog.cl:72-77 + main.cpp:382, so a pixel's samples can never run concurrently
 // anyway).  A lane whose path ends regenerates its next camera ray in the same loop, so the
 // wave stays converged on "traverse -> shade" instead of idling until the longest path of
-// the wave is done.  HBM traffic per sample is ~0: rnds/colors are read once and written
-// once per launch.
+// the wave is done.  The launch is persistent: waves pull (pass, tile) work items from a global
+// counter (k_render); rnds/colors travel through HBM once per pass of 4-8 samples (~7 B/sample).
 //
 // Traversal: own BVH2 (64-B nodes holding both child boxes, 48-B triangle packets), near
 // child first, far child pushed on a per-lane stack that lives in LDS ([entry][lane], bank =
-// lane: conflict-free).  When nodes + packets fit, the workgroup first stages the WHOLE scene
-// in LDS (Cornell box: 1,932 triangles = 132 KiB) and never touches HBM again for geometry.
+// lane: conflict-free).  When the nodes fit (Cornell box: 941 nodes = 60 KB) every workgroup
+// stages them in LDS, re-laid out so that the planes a ray needs are picked by address
+// (stage_nodes, Trav::node_step); packets and larger trees are read through L1/L2.  The kernel is
+// VALU-issue bound: the node visit is written for instruction count.
 //
 // Arithmetic: compiled with -ffp-contract=off; the only fused operations are the explicit
 // fma calls, placed as DESIGN.md section 3 prescribes, so that results can be compared bit
-// for bit with the CPU oracle.  '/' and sqrt are IEEE (hipcc default for HIP), sin/cos/pow are
+// for bit with the CPU oracle (-fno-slp-vectorize: packed f32 ops cost what two scalar ones do,
+// plus the shuffles).  '/' and sqrt are IEEE (hipcc default for HIP), sin/cos/pow are
 // the double-precision polynomial routines below.  Box tests are NOT part of that contract:
 // they are conservative (padded boxes, widened slabs) and only ever cull.
 #include "pt_internal.hpp"
