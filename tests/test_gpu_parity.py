@@ -95,6 +95,23 @@ def test_variants_identical(api, oracle, cb_spec, cb_oracle_scene, lds, block):
     check(sc, fr, "lds=%d block=%d" % (lds, block))
 
 
+def test_whole_scene_in_lds(api, oracle, cb_spec, cb_oracle_scene):
+    """Option lds_scene = 1 requested BEFORE the triangles are uploaded: the builder picks a
+    fatter-leaved tree so that nodes + packets + stacks fit the LDS of one CU, and the kernel
+    stages both (stage_scene).  Same frame as the oracle; the LDS footprint shows the mode was
+    really taken (it is not the default: 0.75x of the nodes-only mode)."""
+    W, H = 96, 72
+    sc = api.Scene(W, H)
+    sc.set_option("lds_scene", 1)
+    sc.load(cb_spec)
+    sc.iterations = 8
+    sc.render(3)
+    assert sc.stat("lds_bytes") > 100 * 1024
+    fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 8, 3)
+    check(sc, fr, "whole scene in LDS")
+    assert sc.stat("segments") == segs
+
+
 @pytest.mark.parametrize("W,H,bounces,spp", [(50, 37, 8, 2), (8, 8, 16, 3), (1, 1, 4, 5), (130, 9, 1, 2), (33, 65, 0, 2)])
 def test_ragged_sizes_and_edge_iterations(api, oracle, cb_spec, cb_oracle_scene, W, H, bounces, spp):
     """Frames that are not multiples of the 8x8 wave tile; iterations = 1 (flat preview,
