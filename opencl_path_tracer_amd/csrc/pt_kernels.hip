@@ -211,17 +211,22 @@ PT_DEV PixelId pixel_of_thread(const RenderParams& p) {
 }
 
 // ---------------------------------------------------------------------------- camera, prog.cl:82-92
-PT_DEV void camera_get_ray(int id, const pt_camera& cam, float rnd1, float rnd2, f3* P, f3* D) {
+// (px, py) = (float)(id % X), (float)(id / X): fixed per pixel, so the render kernel computes them once
+PT_DEV void camera_get_ray_xy(float px, float py, const pt_camera& cam, float rnd1, float rnd2, f3* P, f3* D) {
     const int X = (int)cam.XM;
     const int Y = (int)cam.YM;
-    const float x = (float)(id % X) + rnd1;
-    const float y = (float)(id / X) + rnd2;
+    const float x = px + rnd1;
+    const float y = py + rnd2;
     const f3 right = ldf3(cam.right) * ((2.0f * x) / (float)X - 1.0f);
     const f3 up = ldf3(cam.up) * ((2.0f * y) / (float)Y - 1.0f);
     const f3 pp = (ldf3(cam.lookat) + right) + up;
     const f3 eye = ldf3(cam.eye);
     *P = eye;
     *D = normalize3(pp - eye);
+}
+PT_DEV void camera_get_ray(int id, const pt_camera& cam, float rnd1, float rnd2, f3* P, f3* D) {
+    const int X = (int)cam.XM;
+    camera_get_ray_xy((float)(id % X), (float)(id / X), cam, rnd1, rnd2, P, D);
 }
 
 // ---------------------------------------------------------------------------- traversal
@@ -702,6 +707,8 @@ PT_DEV void render_pixel(const RenderParams& p, const SceneView& sv, const LaneS
     int s = s_begin;
     int bounce = 0;
     bool fresh = true;
+    const int camX = (int)p.cam.XM;
+    const float pix_x = (float)(px.gid % camX), pix_y = (float)(px.gid / camX);      // prog.cl:84-85
     for (;;) {
         if (fresh) {                           // a lane whose path ended starts its next sample right here
             if (s == s_end) break;
@@ -718,7 +725,7 @@ PT_DEV void render_pixel(const RenderParams& p, const SceneView& sv, const LaneS
                 rD = mk(b.x, b.y, b.z);
             } else {
                 const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
-                camera_get_ray(px.gid, p.cam, rnd1, rnd2, &rP, &rD);
+                camera_get_ray_xy(pix_x, pix_y, p.cam, rnd1, rnd2, &rP, &rD);
             }
             bounce = 0;
             fresh = false;
