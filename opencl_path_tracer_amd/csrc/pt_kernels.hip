@@ -377,10 +377,13 @@ struct Trav {
             li = ch.x;
             ri = ch.y;
         } else {
-            const float4 qx = sv.nodes[cur * 4 + 0];
-            const float4 qy = sv.nodes[cur * 4 + 1];
-            const float4 qz = sv.nodes[cur * 4 + 2];
-            const float4 qr = sv.nodes[cur * 4 + 3];
+            // (unsigned 32-bit byte offsets: scalar base + vector offset addressing, no 64-bit address math)
+            const char* nb = reinterpret_cast<const char*>(sv.nodes);
+            const unsigned off = (unsigned)cur << 6;
+            const float4 qx = *reinterpret_cast<const float4*>(nb + off);
+            const float4 qy = *reinterpret_cast<const float4*>(nb + (off + 16u));
+            const float4 qz = *reinterpret_cast<const float4*>(nb + (off + 32u));
+            const float4 qr = *reinterpret_cast<const float4*>(nb + (off + 48u));
             // (plane - P) * inv: ~2 ulp per distance, covered by the 4-ulp widening.  The one-fma form
             // is NOT used here: with min/max picking the planes, a NaN from inf - inf (direction
             // component 0 or underflowing) would be replaced by the OTHER plane's distance and cull
@@ -422,7 +425,9 @@ struct Trav {
     // exact test of packed triangle ti against the ray, keeping the closest (ties: lower rank)
     template <bool COUNT>
     PT_DEV void tri_step(const SceneView& sv, int ti, WorkCount* wc) {
-        const float4 a = sv.tris[ti * 3 + 0], b = sv.tris[ti * 3 + 1], c = sv.tris[ti * 3 + 2];
+        const char* tb = reinterpret_cast<const char*>(sv.tris);
+        const unsigned off = (unsigned)ti * 48u;
+        const float4 a = *reinterpret_cast<const float4*>(tb + off), b = *reinterpret_cast<const float4*>(tb + (off + 16u)), c = *reinterpret_cast<const float4*>(tb + (off + 32u));
         if (COUNT) { wc->tris++; if (first_active_lane()) wc->wtris++; }
         const float t = tri_test(a, b, c, P, D, best_t * 1.000002f);
         if (t > 0.0f) {
