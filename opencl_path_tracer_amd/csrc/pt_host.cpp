@@ -470,6 +470,9 @@ template <class T>
 int upload_vec(pt_context* ctx, T** dptr, const void* src, size_t bytes) {
     if (*dptr) { PT_HIP(ctx, hipFree(*dptr)); *dptr = nullptr; }
     PT_HIP(ctx, hipMalloc((void**)dptr, std::max<size_t>(bytes, 64)));
+    // an (almost) empty array still has one readable, all-zero record: a zero packet can never be
+    // hit, so a leaf reference into an empty scene (the wrapped root's ~0) stays harmless
+    if (bytes < 64) PT_HIP(ctx, hipMemset(*dptr, 0, 64));
     if (bytes) PT_HIP(ctx, hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice));
     return PT_OK;
 }

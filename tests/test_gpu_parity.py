@@ -112,6 +112,56 @@ def test_whole_scene_in_lds(api, oracle, cb_spec, cb_oracle_scene):
     assert sc.stat("segments") == segs
 
 
+@pytest.mark.parametrize("lds_scene", [2, 0])
+@pytest.mark.parametrize("ntris", [0, 1, 2, 5])
+def test_tiny_and_empty_scenes(api, oracle, ntris, lds_scene):
+    """Scenes below the leaf size: the BVH is a wrapped root with one or two (empty) leaf children.
+    0 triangles: every path misses, the frame stays black and each sample draws exactly its two
+    camera-jitter values; 1..5 triangles (an emitter quad, a floor, a tilted mirror): same frame as
+    the oracle on both node paths."""
+    from opencl_path_tracer_amd import scenes
+    mats = list(scenes.BUILTIN_MATERIALS)
+    quad = np.array([[[200, 999, -200], [800, 999, -200], [800, 999, 400]], [[200, 999, -200], [800, 999, 400], [200, 999, 400]],
+                     [[-2000, 0, -2000], [3000, 0, 3000], [3000, 0, -2000]], [[-2000, 0, -2000], [-2000, 0, 3000], [3000, 0, 3000]],
+                     [[300, 100, 900], [700, 100, 900], [500, 700, 600]]], dtype=np.float32)
+    emitter = next(i for i, m in enumerate(mats) if m[6] == 3)
+    mirror = next(i for i, m in enumerate(mats) if m[6] == 1)
+    diffuse = next(i for i, m in enumerate(mats) if m[6] == 0)
+    mati = np.array([emitter, emitter, diffuse, diffuse, mirror], dtype=np.uint16)
+    W, H = 40, 24
+    sc = api.Scene(W, H)
+    sc.set_option("lds_scene", lds_scene)
+    for m in mats:
+        sc.add_Material(*m)
+    if ntris:
+        sc.add_Triangles(api.triangles_from_vertices(quad[:ntris], mati[:ntris]))
+        sc.end_Obj()
+    sc.upload_Triangles()
+    sc.upload_Materials()
+    sc.set_view(60, 0, 0, (0, 0, 0))
+    sc.iterations = 6
+    sc.render(3)
+    if ntris == 0:
+        assert not sc.read_colors().any()
+        assert sc.stat("segments") == W * H * 3
+        seeds = oracle.seed_sequence(W * H)
+        exp = seeds.copy()
+        for _ in range(6):                           # 3 samples x 2 draws
+            exp = ((exp.astype(np.int64) * 48271) % 2147483647).astype(np.int32)
+        assert np.array_equal(sc.read_rnds(), exp)
+        return
+    osc = oracle.OracleScene()
+    for m in mats:
+        osc.add_Material(*m)
+    osc.add_triangles(quad[:ntris], mati[:ntris])
+    osc.end_Obj()
+    cam = oracle.make_camera(60, 0, 0, (0, 0, 0), W, H)
+    fr = oracle.OracleFrame(W, H)
+    segs = fr.render(osc, cam, 6, 0, 3, mode=2, nthreads=8)
+    check(sc, fr, "%d triangles, lds_scene %d" % (ntris, lds_scene))
+    assert sc.stat("segments") == segs
+
+
 @pytest.mark.parametrize("W,H,bounces,spp", [(50, 37, 8, 2), (8, 8, 16, 3), (1, 1, 4, 5), (130, 9, 1, 2), (33, 65, 0, 2)])
 def test_ragged_sizes_and_edge_iterations(api, oracle, cb_spec, cb_oracle_scene, W, H, bounces, spp):
     """Frames that are not multiples of the 8x8 wave tile; iterations = 1 (flat preview,
