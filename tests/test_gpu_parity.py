@@ -235,6 +235,25 @@ def test_other_views_and_custom_seeds(api, oracle, cb_spec, cb_oracle_scene):
         check(sc, fr, "view %s" % (fov,))
 
 
+def test_negative_zero_and_boundary_seeds(api, oracle, cb_spec, cb_oracle_scene):
+    """Seeds the caller may upload but minstd_rand0 never produces: negative (sign-extended to 64 bits
+    as prog.cl:72-77 does; the device takes its generic 64-bit path for them), 0 (a fixed point of
+    the LCG: every draw is 0), 2^31 - 1 (= 0 mod M), 2^31 - 2 and INT_MIN.  Same frame and same
+    final LCG states as the oracle."""
+    W, H = 32, 24
+    special = np.array([0, -1, -2, -48271, -2147483647, -2147483648, 2147483647, 2147483646, 1, 2, -123456789, 1073741824], dtype=np.int64)
+    seeds = np.resize(special, W * H).astype(np.int32)
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.upload_seeds(seeds)
+    sc.iterations = 6
+    sc.render(3)
+    cam = oracle.make_camera(cb_spec.fov, cb_spec.yaw, cb_spec.pitch, cb_spec.shift, W, H)
+    fr = oracle.OracleFrame(W, H, seed_default=False)
+    fr.rnds()[:] = seeds
+    fr.render(cb_oracle_scene, cam, 6, 0, 3, nthreads=16)
+    check(sc, fr, "special seeds")
+
+
 def test_sample_zero_resets_accumulator(api, oracle, cb_spec, cb_oracle_scene):
     """Key events set current_sample = 0 (main.cpp:1046,1102-1130); the kernel then restarts the
     running mean from black (prog.cl:312-314) while the LCG streams continue."""
