@@ -235,6 +235,38 @@ def test_other_views_and_custom_seeds(api, oracle, cb_spec, cb_oracle_scene):
         check(sc, fr, "view %s" % (fov,))
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_glossy_and_unknown_materials(api, oracle, variant):
+    """The Cornell box re-dressed with the materials the default scene does not use: diffuse with a
+    specular lobe (ks != 0, shininess 200: the double-precision pow of the arithmetic contract,
+    prog.cl:337-339), gold (mirror with a coloured Fresnel term), the brighter emitter, and a material
+    of a type the kernel does not know (prog.cl:329-366 has no branch for it: the ray is left
+    unchanged and hits the same surface again until the bounce limit).  Same frame as the oracle."""
+    import copy
+    from opencl_path_tracer_amd import scenes
+    spec = copy.deepcopy(scenes.cornell_box())
+    spec.materials.append(((0.2, 0.2, 0.2), (0.1, 0.1, 0.1), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 10.0, 7))
+    unknown = len(spec.materials) - 1
+    remap = {scenes.WHITE_DIFFUSE: scenes.PURPLE_SPECULAR, scenes.RED_DIFFUSE: scenes.BLACK_SPECULAR, scenes.LAMP: scenes.SUN,
+             scenes.CHROMIUM: scenes.GOLD}
+    objs = []
+    for verts, mati in spec.objects:
+        m = np.array([remap.get(int(x), int(x)) for x in mati], dtype=np.uint16)
+        objs.append((verts, m))
+    objs[0][1][2:4] = unknown                    # the far wall
+    spec.objects = objs
+    W, H = 96, 64
+    sc = api.Scene(W, H).load(spec)
+    sc.set_option("variant", variant)
+    sc.iterations = 8
+    sc.render(3)
+    osc = oracle.load_scene(spec)
+    fr, segs = oracle_render(oracle, osc, spec, W, H, 8, 3)
+    check(sc, fr, "glossy/unknown materials, variant %d" % variant)
+    assert sc.stat("segments") == segs
+    assert float(fr.colors().sum()) > 0
+
+
 def test_negative_zero_and_boundary_seeds(api, oracle, cb_spec, cb_oracle_scene):
     """Seeds the caller may upload but minstd_rand0 never produces: negative (sign-extended to 64 bits
     as prog.cl:72-77 does; the device takes its generic 64-bit path for them), 0 (a fixed point of
