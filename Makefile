@@ -7,8 +7,23 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-s
 
 all: $(PKG)/libptamd.so oracle tests/cpp/dropin
 
-$(PKG)/libptamd.so: $(CSRC)/pt_host.cpp $(CSRC)/pt_obj.cpp $(CSRC)/pt_kernels.hip $(CSRC)/pt_lbvh.hip $(CSRC)/pt_internal.hpp include/pt_api.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/pt_host.cpp $(CSRC)/pt_obj.cpp $(CSRC)/pt_kernels.hip $(CSRC)/pt_lbvh.hip
+SRCS    := $(CSRC)/pt_host.cpp $(CSRC)/pt_obj.cpp $(CSRC)/pt_kernels.hip $(CSRC)/pt_wavefront.hip $(CSRC)/pt_debug.hip $(CSRC)/pt_lbvh.hip $(CSRC)/pt_comm.hip $(CSRC)/pt_image.cpp
+HDRS    := $(CSRC)/pt_internal.hpp $(CSRC)/pt_device.hpp include/pt_api.h
+OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
+
+$(PKG)/libptamd.so: $(OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS) -ldl
+
+build/%.o: $(CSRC)/% $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) $(ABFLAGS) -c -o $@ $<
+
+# A/B builds of the kernels for experiments: make ab AB=name ABFLAGS="-DPT_X=1" -> $(PKG)/libptamd_name.so
+# (select it with PTAMD_LIB=... ; never loaded by default)
+ab:
+	@mkdir -p build/ab_$(AB)
+	for f in $(SRCS); do $(HIPCC) $(HIPFLAGS) $(ABFLAGS) -c -o build/ab_$(AB)/$$(basename $$f).o $$f & done; wait
+	$(HIPCC) $(HIPFLAGS) -shared -o $(PKG)/libptamd_$(AB).so build/ab_$(AB)/*.o -ldl
 
 tests/cpp/dropin: tests/cpp/dropin_main.cpp include/pt_scene.hpp include/pt_api.h $(PKG)/libptamd.so
 	g++ -O1 -std=c++14 -Iinclude -o $@ tests/cpp/dropin_main.cpp -L$(PKG) -lptamd -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -Wl,-rpath,/opt/rocm/lib
@@ -17,7 +32,7 @@ oracle:
 	$(MAKE) -C oracle -s
 
 clean:
-	rm -f $(PKG)/libptamd.so tests/cpp/dropin
+	rm -rf $(PKG)/libptamd*.so tests/cpp/dropin build
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean ab

@@ -36,7 +36,8 @@ extern "C" {
 #define PT_ENODEVICE (-2)  /* no HIP device, or the device is not gfx950-compatible */
 #define PT_EHIP (-3)       /* a HIP runtime call failed (text in pt_last_error) */
 #define PT_ESCENE (-4)     /* scene cannot be built (e.g. the reference's build would not terminate) */
-#define PT_EIO (-5)        /* OBJ/MTL file could not be read or parsed */
+#define PT_EIO (-5)        /* a file could not be read, parsed or written */
+#define PT_ECOMM (-6)      /* RCCL is unavailable or a collective failed (text in pt_last_error) */
 
 /* ---- value types, byte-compatible with the reference's device structs ------------ */
 typedef struct { float s[4]; } pt_float3;                 /* cl_float3: 16 B, .s[3] is padding */
@@ -121,6 +122,7 @@ int pt_sync(pt_context* ctx);                                        /* queue.fi
 /* ---- readback (the reference never reads back; its only output is a GL texture) ----- */
 int pt_local_pixel_count(const pt_context* ctx, int64_t* out);
 int pt_local_pixel_ids(const pt_context* ctx, int32_t* out_ids, int64_t n);  /* global pixel id of each local pixel */
+int pt_slab_pixel_count(const pt_context* ctx, int64_t* out);       /* max over ranks of the local pixel count */
 int pt_read_colors(pt_context* ctx, float* out_rgba, int64_t npix);  /* buffer_colors: float3 @ 16 B stride */
 int pt_read_rnds(pt_context* ctx, int32_t* out, int64_t npix);       /* buffer_rnds */
 int pt_read_rays(pt_context* ctx, pt_ray* out, int64_t npix);        /* buffer_rays */
@@ -128,38 +130,65 @@ int pt_read_rays(pt_context* ctx, pt_ray* out, int64_t npix);        /* buffer_r
  * prog.cl:380); which = 0 Reinhard, 1 = filt_im (3x3 median + filmic, prog.cl:391-427). */
 int pt_resolve_ldr(pt_context* ctx, int32_t which, float* out_rgba, int64_t npix);
 
+/* ---- multi-GPU frame assembly (SURVEY 8b "RCCL communicator per context", 8e) ----------
+ * The reference is single-device (main.cpp:466-476); a host that tiles the frame over N contexts with
+ * pt_create_tiled assembles it with these.  One process (or thread) per GPU:
+ *   rank 0: pt_comm_unique_id(id); every rank receives the 128 bytes by the host's own means (MPI,
+ *   a file, torch.distributed ...); every rank: pt_comm_init(ctx, id); after rendering, every rank:
+ *   pt_gather_frame(ctx) -- ONE ncclAllGather of the ranks' radiance slabs over RCCL/xGMI on the context's
+ *   stream + a de-interleave kernel -- leaves the whole width x height frame (float3 @ 16 B, global pixel
+ *   order) in device memory on every rank.  world = 1 needs no communicator. */
+#define PT_COMM_ID_BYTES 128
+int pt_comm_unique_id(void* id128);                                  /* ncclGetUniqueId */
+int pt_comm_init(pt_context* ctx, const void* id128);                /* ncclCommInitRank(world, id, rank) of pt_create_tiled */
+int pt_gather_frame(pt_context* ctx);
+void* pt_device_frame(pt_context* ctx);                              /* the assembled frame (world = 1: the colors buffer) */
+int pt_frame_size(const pt_context* ctx, int32_t* width, int32_t* height, int64_t* npix);
+int pt_read_frame(pt_context* ctx, float* out_rgba, int64_t npix);   /* npix = width * height of the GLOBAL frame */
+
+/* ---- image files: what the reference shows through its GL blit, main.cpp:1019-1039 -------
+ * PFM = the HDR `colors` (the parity target) of the assembled frame; PPM = an LDR resolve (`which` as in
+ * pt_resolve_ldr; the tone map's NaN for black pixels, prog.cl:265-267, is written as 0), world = 1 only.
+ * The pt_image_* forms write a caller-supplied host buffer (float3 @ 16 B, row 0 = bottom of the view). */
+int pt_write_pfm(pt_context* ctx, const char* path);
+int pt_write_ppm(pt_context* ctx, const char* path, int32_t which);
+int pt_image_write_pfm(const char* path, const float* rgba, int32_t width, int32_t height);
+int pt_image_write_ppm(const char* path, const float* rgba, int32_t width, int32_t height);
+
 /* ---- plumbing: device memory, streams, options, statistics --------------------------- */
 /* Use caller-owned device buffers (e.g. torch tensors) for colors (16 B/px) and rnds (4 B/px)
- * of the LOCAL pixels; current contents are copied in.  NULL keeps the internal buffer. */
+ * of the LOCAL pixels; current contents are copied in.  NULL keeps the internal buffer.  In a tiled
+ * context the colors buffer must hold pt_slab_pixel_count() pixels (the largest rank's count: the
+ * all-gather sends equal slabs). */
 int pt_bind_framebuffer(pt_context* ctx, void* d_colors, void* d_rnds);
 void* pt_device_colors(pt_context* ctx);
 void* pt_device_rnds(pt_context* ctx);
 int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStream_t; NULL = default stream */
 /* options (key, value):
  *   "variant"      0 megakernel (default), 1 wavefront (stream-compacted, path state in HBM)
- *   "bvh_policy"   0 host SAH (default), 1-3 host variants (leaf policies), 4 device LBVH; set before upload
- *   "lds_scene"    megakernel: 2 (default) stage the BVH nodes in LDS when they fit (<= 64 KB, <= 4096
- *                  triangles), 1 stage nodes and triangle packets, 0 everything through L1/L2
- *   "block"        threads per workgroup of the megakernel (64..1024)
- *   "min_waves"    __launch_bounds__ waves/SIMD of the megakernel (1,4,5,6,8; default 4)
- *   "traversal"    0 while-while (default), 1 wave-voting, n >= 2 sliced (n-1 rounds per trip)
+ *   "bvh_policy"   0 host SAH (default), 2 / 3 host SAH with leaves forced to <= 4 / <= 8 triangles, 4 device LBVH;
+ *                  set before the triangles are uploaded
+ *   "lds_scene"    2 (default) every workgroup stages BVH nodes in LDS: the whole tree when it fits (<= 64 KB,
+ *                  <= 4096 triangles), otherwise its top (the treelet); 0 every node through L1/L2
+ *   "treelet"      nodes of a large tree to stage: -1 (default) what fits next to one 1,024-thread workgroup's
+ *                  stacks (~750-1,000), 0 none, 2..2048; set before the triangles are uploaded
  *   "persistent"   1 (default) megakernel grid only fills the chip and every wave pulls its next 8x8
  *                  tile from a global counter; 0 one workgroup per group of tiles
  *   "chunk_spp"    persistent megakernel work items: n > 0 (pass, tile) items of n samples, chained per tile
  *                  through memory inside ONE launch; 0 whole tiles; -1 (default) automatic
- *   "pixel_map"    0 one wave = one 8x8 tile (default), 1 strided
  *   "sah_visit_cost"  SAH price of one node visit in tenths of a triangle test (default 10; set before
  *                  the triangles are uploaded.  Measured: 5 / 10 / 15 / 20 -> 1006 / 1448 / 1393 / 1266 Msamples/s)
  *   "cost_binning" 0/1 wavefront: separate ray streams for rays touching a complex object's box
  *   "timing"       0/1 record HIP events around the dominant kernel ("kernel_ms" statistic)
  *   "count_work"   0/1 also count node visits / triangle tests (slower kernel instance)
  *   "reset_stats"  1 zero all statistics
- *   "debug_repeat" n extra timed launches in pt_debug_closest_hit */
+ *   "debug_repeat" 0..1000 extra timed launches in pt_debug_closest_hit */
 int pt_set_option(pt_context* ctx, const char* key, int64_t value);
 /* stats: "segments" path segments executed since the last reset, "samples", "kernel_ms" (sum of
  * HIP-event durations of the dominant kernel), "kernel_launches", "bvh_nodes", "bvh_depth",
- * "bvh_build_ms", "bvh_on_device", "triangles", "lds_bytes", and with count_work: "node_visits",
- * "tri_tests", "wave_node_steps", "wave_tri_steps" */
+ * "bvh_build_ms", "bvh_on_device", "triangles", "lds_bytes", "node_mode" (0 whole tree in LDS, 1 L1/L2 only,
+ * 2 treelet), "treelet_nodes", and with count_work: "node_visits", "tri_tests", "wave_node_steps",
+ * "wave_tri_steps", "tile_lane_steps" */
 int pt_get_stat(pt_context* ctx, const char* key, double* out);
 
 /* ---- introspection for tests (host data; no device work) ----------------------------- */
@@ -176,6 +205,12 @@ int pt_debug_scene_sizes(const pt_context* ctx, int64_t* ntris, int64_t* nmats, 
 int pt_debug_scene_copy(const pt_context* ctx, pt_triangle* tris, pt_material* mats, int32_t* obj_begin);
 /* the reference's traversal encounter rank of each triangle, in add order */
 int pt_debug_encounter_rank(const pt_context* ctx, int32_t* out, int64_t n);
+/* frame assembly: out[gid] = index into the rank-major all-gather buffer (slab_stride pixels per rank) that
+ * global pixel gid is read from -- the host statement of the de-interleave kernel's map (no device work) */
+int pt_debug_gather_index(int32_t width, int32_t height, int32_t world, int32_t rows_per_block, int64_t slab_stride, int64_t* out);
+/* runs ONLY the de-interleave kernel of pt_gather_frame on a caller-supplied all-gather buffer
+ * (world x slab pixels, float4 each) with the context's frame size and tiling */
+int pt_debug_deinterleave(pt_context* ctx, const float* gathered_rgba, int64_t n_pixels, float* out_frame_rgba);
 
 #ifdef __cplusplus
 }

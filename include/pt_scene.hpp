@@ -34,11 +34,13 @@ struct Triangle : pt_triangle {                        // main.cpp:139-182
     Triangle(cl_float3 r1_, cl_float3 r2_, cl_float3 r3_, unsigned short mati_) { pt_triangle_init(this, r1_.s, r2_.s, r3_.s, mati_); }
 };
 
-struct Globals {                                       // main.cpp:20-39
-    int screen_width = 192 * 8, screen_height = 108 * 8;
-    int iterations = 1;
-    float global_fov = 60.0f, global_yaw = 0.0f, global_pitch = 0.0f;
-    cl_float3 global_shift = {{0.0f, 0.0f, 0.0f, 0.0f}};
+struct Globals {                                       // the shipped values of main.cpp:20-39
+    int screen_width = 192 * 8, screen_height = 108 * 8;                                 // main.cpp:20-21
+    int iterations = 1;                                                                  // main.cpp:27
+    float global_fov = 75.0f;                                                            // main.cpp:30
+    float global_yaw = (float)(-13.800002 - 50), global_pitch = (float)(5.599997 + 10);   // main.cpp:31-32 (double arithmetic, narrowed)
+    cl_float3 global_shift = {{265.055481f, 162.305969f, 360.414001f, 0.0f}};            // main.cpp:39
+    // (the "canonical" view the reference keeps in comments, main.cpp:33-35,40: fov 60, yaw 0, pitch 0, shift 0)
 };
 
 struct Camera : pt_camera {                            // main.cpp:306-348

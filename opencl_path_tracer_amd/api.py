@@ -20,9 +20,11 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libptamd.so")
+# PTAMD_LIB: an A/B build of the same library (`make ab`), for kernel experiments only
+_LIB_PATH = os.environ.get("PTAMD_LIB") or os.path.join(_HERE, "libptamd.so")
 
-PT_OK, PT_EINVAL, PT_ENODEVICE, PT_EHIP, PT_ESCENE, PT_EIO = 0, -1, -2, -3, -4, -5
+PT_OK, PT_EINVAL, PT_ENODEVICE, PT_EHIP, PT_ESCENE, PT_EIO, PT_ECOMM = 0, -1, -2, -3, -4, -5, -6
+PT_COMM_ID_BYTES = 128
 
 MATERIAL = np.dtype([("kd", "<f4", 4), ("ks", "<f4", 4), ("emission", "<f4", 4), ("F0", "<f4", 4),
                      ("n", "<f4"), ("shininess", "<f4"), ("type", "<i4"), ("_pad", "<i4")])
@@ -43,6 +45,8 @@ EXPORTS = [
     "pt_resolve_ldr", "pt_bind_framebuffer", "pt_device_colors", "pt_device_rnds", "pt_set_stream",
     "pt_set_option", "pt_get_stat", "pt_debug_bvh_sizes", "pt_debug_bvh_copy", "pt_debug_encounter_rank",
     "pt_debug_scene_sizes", "pt_debug_scene_copy", "pt_debug_closest_hit",
+    "pt_slab_pixel_count", "pt_frame_size", "pt_comm_unique_id", "pt_comm_init", "pt_gather_frame", "pt_device_frame", "pt_read_frame",
+    "pt_write_pfm", "pt_write_ppm", "pt_image_write_pfm", "pt_image_write_ppm", "pt_debug_gather_index", "pt_debug_deinterleave",
 ]
 
 
@@ -107,6 +111,19 @@ def _load():
     sig("pt_debug_scene_sizes", C.c_int, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64))
     sig("pt_debug_scene_copy", C.c_int, vp, vp, vp, vp)
     sig("pt_debug_closest_hit", C.c_int, vp, vp, i64, vp, vp)
+    sig("pt_slab_pixel_count", C.c_int, vp, C.POINTER(i64))
+    sig("pt_frame_size", C.c_int, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64))
+    sig("pt_comm_unique_id", C.c_int, vp)
+    sig("pt_comm_init", C.c_int, vp, vp)
+    sig("pt_gather_frame", C.c_int, vp)
+    sig("pt_device_frame", vp, vp)
+    sig("pt_read_frame", C.c_int, vp, vp, i64)
+    sig("pt_write_pfm", C.c_int, vp, C.c_char_p)
+    sig("pt_write_ppm", C.c_int, vp, C.c_char_p, i32)
+    sig("pt_image_write_pfm", C.c_int, C.c_char_p, vp, i32, i32)
+    sig("pt_image_write_ppm", C.c_int, C.c_char_p, vp, i32, i32)
+    sig("pt_debug_gather_index", C.c_int, i32, i32, i32, i32, i64, vp)
+    sig("pt_debug_deinterleave", C.c_int, vp, vp, i64, vp)
     return L
 
 
@@ -149,6 +166,37 @@ def triangles_from_vertices(verts, mati):
     out = np.zeros(verts.shape[0], dtype=TRIANGLE)
     LIB.pt_triangles_init(_ptr(out), _ptr(verts), _ptr(mati), verts.shape[0])
     return out
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI: 128 bytes for rank 0 to hand to every rank."""
+    buf = (C.c_ubyte * PT_COMM_ID_BYTES)()
+    rc = LIB.pt_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != PT_OK:
+        raise PtError(rc, (LIB.pt_last_error(None) or b"").decode())
+    return bytes(buf)
+
+
+def gather_index(width, height, world, rows_per_block, slab_stride):
+    out = np.empty(width * height, dtype=np.int64)
+    rc = LIB.pt_debug_gather_index(width, height, world, rows_per_block, slab_stride, _ptr(out))
+    if rc != PT_OK:
+        raise PtError(rc, "pt_debug_gather_index")
+    return out
+
+
+def write_pfm(path, rgba, width, height):
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32).reshape(width * height, 4)
+    rc = LIB.pt_image_write_pfm(os.fsencode(path), _ptr(rgba), width, height)
+    if rc != PT_OK:
+        raise PtError(rc, "cannot write %s" % path)
+
+
+def write_ppm(path, rgba, width, height):
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32).reshape(width * height, 4)
+    rc = LIB.pt_image_write_ppm(os.fsencode(path), _ptr(rgba), width, height)
+    if rc != PT_OK:
+        raise PtError(rc, "cannot write %s" % path)
 
 
 class Scene:
@@ -306,6 +354,41 @@ class Scene:
     def read_rays(self):
         out = np.empty(self.local_pixels, dtype=RAY)
         self._ck(LIB.pt_read_rays(self._h, _ptr(out), out.size))
+        return out
+
+    # -- frame assembly over RCCL (one process per GPU; the 128-byte id travels by the host's own means)
+    @property
+    def slab_pixels(self):
+        v = C.c_int64()
+        self._ck(LIB.pt_slab_pixel_count(self._h, C.byref(v)))
+        return v.value
+
+    def comm_init(self, id_bytes):
+        buf = (C.c_ubyte * PT_COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        self._ck(LIB.pt_comm_init(self._h, C.cast(buf, C.c_void_p)))
+
+    def gather_frame(self):
+        self._ck(LIB.pt_gather_frame(self._h))
+
+    def device_frame(self):
+        return LIB.pt_device_frame(self._h)
+
+    def read_frame(self):
+        out = np.empty((self.width * self.height, 4), dtype=np.float32)
+        self._ck(LIB.pt_read_frame(self._h, _ptr(out), out.shape[0]))
+        return out
+
+    # -- image files (what the reference shows through its GL blit, main.cpp:1019-1039)
+    def write_pfm(self, path):
+        self._ck(LIB.pt_write_pfm(self._h, os.fsencode(path)))
+
+    def write_ppm(self, path, which=0):
+        self._ck(LIB.pt_write_ppm(self._h, os.fsencode(path), int(which)))
+
+    def debug_deinterleave(self, gathered):
+        gathered = np.ascontiguousarray(gathered, dtype=np.float32).reshape(-1, 4)
+        out = np.empty((self.width * self.height, 4), dtype=np.float32)
+        self._ck(LIB.pt_debug_deinterleave(self._h, _ptr(gathered), gathered.shape[0], _ptr(out)))
         return out
 
     def resolve_ldr(self, which=0):

@@ -1,0 +1,728 @@
+// pt_device.hpp -- gfx950 device code shared by the kernel translation units of libptamd.so
+// (pt_kernels.hip: megakernel; pt_wavefront.hip: stream-compacted variant; pt_debug.hip: test entry
+// points).  Everything here is __device__ __forceinline__.
+//
+// Arithmetic: compiled with -ffp-contract=off; the only fused operations are the explicit fma calls,
+// placed as DESIGN.md section 3 prescribes, so that results can be compared bit for bit with the CPU
+// oracle (-fno-slp-vectorize: packed f32 ops cost what two scalar ones do, plus the shuffles).  '/'
+// and sqrt are IEEE (hipcc default for HIP), sin/cos/pow are the double-precision polynomial routines
+// below.  Box tests are NOT part of that contract: they are conservative (padded boxes, widened
+// slabs) and only ever cull what the exact triangle test would reject.
+#pragma once
+
+#include "pt_internal.hpp"
+
+// A/B switch of the slab test for nodes read from global memory (1: one fma per plane, planes picked
+// by the sign of the direction; 0: round 1's (plane - P) * inv with min/max)
+#ifndef PT_GLOBAL_SLAB_FMA
+#define PT_GLOBAL_SLAB_FMA 1
+#endif
+
+namespace ptamd {
+
+// ---------------------------------------------------------------------------- small math
+struct f3 {
+    float x, y, z;
+};
+#define PT_DEV __device__ __forceinline__
+
+PT_DEV f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV f3 ldf3(const pt_float3& p) { return mk(p.s[0], p.s[1], p.s[2]); }
+PT_DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+PT_DEV f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+PT_DEV float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PT_DEV double fmad_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// u*s + w, one fma per component
+PT_DEV f3 madd(f3 u, float s, f3 w) { return mk(fmaf_(u.x, s, w.x), fmaf_(u.y, s, w.y), fmaf_(u.z, s, w.z)); }
+PT_DEV float dot3(f3 a, f3 b) { return fmaf_(a.z, b.z, fmaf_(a.y, b.y, a.x * b.x)); }
+PT_DEV f3 cross3(f3 a, f3 b) {
+    return mk(fmaf_(a.y, b.z, -(a.z * b.y)), fmaf_(a.z, b.x, -(a.x * b.z)), fmaf_(a.x, b.y, -(a.y * b.x)));
+}
+PT_DEV f3 normalize3(f3 a) {
+    const float s = 1.0f / __builtin_sqrtf(dot3(a, a));
+    return a * s;
+}
+PT_DEV float max0(float c) { return c > 0.0f ? c : 0.0f; }
+
+// ---- spec math: double polynomials, rounded once to float
+PT_DEV void spec_sincos(float theta, float* s, float* c) {
+    const double t = (double)theta;
+    const int q = (int)fmad_(t, 0.63661977236758138, 0.5);
+    const double qd = (double)q;
+    double r = fmad_(qd, -1.5707963267948966, t);
+    r = fmad_(qd, -6.123233995736766e-17, r);
+    const double z = r * r;
+    double ps = 1.6059043836821613e-10;
+    ps = fmad_(ps, z, -2.505210838544172e-08);
+    ps = fmad_(ps, z, 2.7557319223985893e-06);
+    ps = fmad_(ps, z, -0.0001984126984126984);
+    ps = fmad_(ps, z, 0.008333333333333333);
+    ps = fmad_(ps, z, -0.16666666666666666);
+    const double sr = fmad_(r * z, ps, r);
+    double pc = -1.1470745597729725e-11;
+    pc = fmad_(pc, z, 2.08767569878681e-09);
+    pc = fmad_(pc, z, -2.755731922398589e-07);
+    pc = fmad_(pc, z, 2.48015873015873e-05);
+    pc = fmad_(pc, z, -0.001388888888888889);
+    pc = fmad_(pc, z, 0.041666666666666664);
+    pc = fmad_(pc, z, -0.5);
+    const double cr = fmad_(z, pc, 1.0);
+    const int k = q & 3;
+    const double sv = (k == 0) ? sr : (k == 1) ? cr : (k == 2) ? -sr : -cr;
+    const double cv = (k == 0) ? cr : (k == 1) ? -sr : (k == 2) ? -cr : sr;
+    *s = (float)sv;
+    *c = (float)cv;
+}
+
+PT_DEV float spec_pow5(float x) {
+    const float x2 = x * x;
+    const float x4 = x2 * x2;
+    return x4 * x;
+}
+
+PT_DEV float spec_pow(float x, float y) {
+    if (y == 0.0f) return 1.0f;
+    if (x != x || y != y) return __builtin_nanf("");
+    if (x < 0.0f) return __builtin_nanf("");
+    if (x == 0.0f) return y > 0.0f ? 0.0f : __builtin_inff();
+    if (__builtin_isinf(x)) return y > 0.0f ? __builtin_inff() : 0.0f;
+    const double xd = (double)x;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(xd);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m = __longlong_as_double((long long)bits);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double sdiv = f / (2.0 + f);
+    const double z = sdiv * sdiv;
+    double p = 0.10526315789473684;
+    p = fmad_(p, z, 0.11764705882352941);
+    p = fmad_(p, z, 0.13333333333333333);
+    p = fmad_(p, z, 0.15384615384615385);
+    p = fmad_(p, z, 0.18181818181818182);
+    p = fmad_(p, z, 0.22222222222222221);
+    p = fmad_(p, z, 0.2857142857142857);
+    p = fmad_(p, z, 0.4);
+    p = fmad_(p, z, 0.66666666666666663);
+    p = fmad_(p, z, 2.0);
+    const double lnm = sdiv * p;
+    const double lg2 = fmad_(lnm, 1.4426950408889634, (double)e);
+    const double w = (double)y * lg2;
+    if (!(w > -126.0)) return 0.0f;
+    if (w >= 128.0) return __builtin_inff();
+    const double nd = __builtin_floor(w + 0.5);
+    const double g = (w - nd) * 0.6931471805599453;
+    double q = 2.08767569878681e-09;
+    q = fmad_(q, g, 2.505210838544172e-08);
+    q = fmad_(q, g, 2.755731922398589e-07);
+    q = fmad_(q, g, 2.7557319223985893e-06);
+    q = fmad_(q, g, 2.48015873015873e-05);
+    q = fmad_(q, g, 0.0001984126984126984);
+    q = fmad_(q, g, 0.001388888888888889);
+    q = fmad_(q, g, 0.008333333333333333);
+    q = fmad_(q, g, 0.041666666666666664);
+    q = fmad_(q, g, 0.16666666666666666);
+    q = fmad_(q, g, 0.5);
+    q = fmad_(q, g, 1.0);
+    q = fmad_(q, g, 1.0);
+    const unsigned long long sb = (unsigned long long)((long long)nd + 1023) << 52;
+    const double sc = __longlong_as_double((long long)sb);
+    return (float)(q * sc);
+}
+
+// ---- LCG, prog.cl:72-77: n = (ulong)seed * 48271 % 2147483647.
+// For seed >= 0 the product is < 2^47 and the modulus is the Mersenne number 2^31 - 1:
+// n = hi * 2^31 + lo = hi + lo (mod M) with hi < 2^16, so one conditional subtraction finishes it
+// (8 32-bit instructions instead of the ~30 of a 64-bit multiply and remainder).  A negative seed
+// (only possible for a seed the caller uploaded; every output is in [0, M)) sign-extends to 64 bits
+// as in the reference and takes the generic path.
+PT_DEV float lcg_rand(int& seed) {
+    unsigned n;
+    if (seed >= 0) {
+        const unsigned s = (unsigned)seed;
+        const unsigned plo = s * 48271u, phi = __umulhi(s, 48271u);
+        const unsigned t = (plo & 0x7fffffffu) + ((phi << 1) | (plo >> 31));
+        n = min(t, t - 2147483647u);
+    } else {
+        unsigned long long w = (unsigned long long)(long long)seed;
+        w = (w * 48271ull) % 2147483647ull;
+        n = (unsigned)w;
+    }
+    seed = (int)n;
+    return (float)n / 2147483648.0f;
+}
+
+// ---------------------------------------------------------------------------- pixel map
+// One wave covers an 8x8 pixel tile of the LOCAL frame (width x local_rows).
+struct PixelId {
+    int li;   // local pixel index (buffer index), -1 = none
+    int gid;  // global pixel id (what prog.cl calls id)
+};
+PT_DEV PixelId pixel_of_wave(const RenderParams& p, int wave) {
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (p.width + 7) >> 3;
+    const int ty = wave / tiles_x, tx = wave - ty * tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int lrow = ty * 8 + (lane >> 3);
+    PixelId r;
+    if (x >= p.width || lrow >= p.local_rows) {
+        r.li = -1;
+        r.gid = 0;
+        return r;
+    }
+    const int grow = ((lrow / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (lrow % p.rows_per_block);
+    r.li = lrow * p.width + x;
+    r.gid = grow * p.width + x;
+    return r;
+}
+
+PT_DEV PixelId pixel_of_thread(const RenderParams& p) {
+    return pixel_of_wave(p, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+}
+
+// ---------------------------------------------------------------------------- camera, prog.cl:82-92
+// (px, py) = (float)(id % X), (float)(id / X): fixed per pixel, so the render kernel computes them once
+PT_DEV void camera_get_ray_xy(float px, float py, const pt_camera& cam, float rnd1, float rnd2, f3* P, f3* D) {
+    const int X = (int)cam.XM;
+    const int Y = (int)cam.YM;
+    const float x = px + rnd1;
+    const float y = py + rnd2;
+    const f3 right = ldf3(cam.right) * ((2.0f * x) / (float)X - 1.0f);
+    const f3 up = ldf3(cam.up) * ((2.0f * y) / (float)Y - 1.0f);
+    const f3 pp = (ldf3(cam.lookat) + right) + up;
+    const f3 eye = ldf3(cam.eye);
+    *P = eye;
+    *D = normalize3(pp - eye);
+}
+PT_DEV void camera_get_ray(int id, const pt_camera& cam, float rnd1, float rnd2, f3* P, f3* D) {
+    const int X = (int)cam.XM;
+    camera_get_ray_xy((float)(id % X), (float)(id / X), cam, rnd1, rnd2, P, D);
+}
+
+// ---------------------------------------------------------------------------- traversal
+// Where the BVH nodes are read from (template parameter of Trav and of the kernels):
+//   kNodesLds      every node is staged in LDS by the workgroup (stage_nodes), re-laid out for the
+//                  ray (swizzled box quads, 16-bit child references, 16-bit stack entries).  Scenes
+//                  of up to ~1,000 nodes (Cornell box: 941).
+//   kNodesGlobal   nodes are read from global memory (L1/L2) as the host packed them.
+//   kNodesTreelet  the top `treelet` nodes of a large tree -- the host re-indexes the tree so that
+//                  the nodes with the largest boxes are nodes [0, treelet) -- are staged in LDS AS THEY
+//                  ARE, the rest stays in global memory, and a visit reads its node through a generic
+//                  (flat) pointer that each lane points at its LDS copy or at global memory: one
+//                  instruction stream for both, no divergence between lanes above and below the cut.
+//                  References stay 32-bit.  MESH-100k / MESH-1M (50 k / 505 k nodes).
+struct SceneView {
+    const float4* nodes;       // global memory, host layout (unused by kNodesLds)
+    const float4* lds_nodes;   // staged copy (kNodesLds: all nodes; kNodesTreelet: nodes [0, treelet))
+    const float4* tris;        // packets, global memory
+    const TriMeta* meta;       // global memory
+    unsigned treelet;          // kNodesTreelet: node indices below this are read from lds_nodes
+};
+
+// prog.cl:94-112 on one packet; returns t (> 0) or -1.  `limit` is the current closest t: a
+// triangle whose t is clearly larger can neither win nor tie, so it is dropped before the exact
+// (IEEE-divide) evaluation.  Both early-outs are conservative: whatever the exact test would
+// accept with t <= best_t passes them (t > 0 needs num and den of the same non-zero sign; the
+// reciprocal estimate is within 2 ulp and the margin is 16 ulp).
+// QUOT picks how the two early-outs are evaluated (same accepted set up to harmless extras):
+//   true : from the estimated quotient alone, q = num * rcp(den): not negative and not above the
+//          limit (q = 0, -0 and NaN pass and are sorted out by the exact evaluation) -- fewest VALU
+//          instructions, +2.7 % on the VALU-bound LDS node path;
+//   false: four sign compares first, the reciprocal only for same-sign pairs -- 3 % faster on the
+//          L1/L2 node path, where the 8-clock v_rcp on every test costs more than it saves.
+template <bool QUOT>
+PT_DEV float tri_test(const float4 a, const float4 b, const float4 c, f3 P, f3 Vd, float limit) {
+    const f3 r1 = mk(a.x, a.y, a.z), r2 = mk(a.w, b.x, b.y), r3 = mk(b.z, b.w, c.x), N = mk(c.y, c.z, c.w);
+    const float num = dot3(r1 - P, N), den = dot3(Vd, N);
+    float res = -1.0f;
+    bool cand;
+    if (QUOT) {
+        const float q = num * __builtin_amdgcn_rcpf(den);
+        cand = !(q < 0.0f) && !(q > limit);
+    } else {
+        const bool same_sign = (num > 0.0f && den > 0.0f) || (num < 0.0f && den < 0.0f);
+        cand = same_sign && num * __builtin_amdgcn_rcpf(den) <= limit;
+    }
+    if (cand) {
+        const float t = num / den;
+        const f3 pt = madd(Vd, t, P);
+        const float c1 = dot3(cross3(r2 - r1, pt - r1), N);
+        const float c2 = dot3(cross3(r3 - r2, pt - r2), N);
+        const float c3 = dot3(cross3(r1 - r3, pt - r3), N);
+        const bool ok = !(t < 0.0f) && (c1 >= 0.0f) && (c2 >= 0.0f) && (c3 >= 0.0f) && (t > 0.0f);
+        res = ok ? t : -1.0f;
+    }
+    return res;
+}
+
+// Per-lane traversal stack in LDS, laid out [entry][lane] (consecutive lanes -> consecutive
+// banks).  Entry 0 holds a "finished" sentinel, so popping never has to test for an empty stack.
+template <class T>
+struct LaneStack {
+    T* base;        // already offset by the lane
+    int stride;     // entries are `stride` elements apart
+};
+
+struct WorkCount {
+    unsigned nodes, tris;     // per-lane visits / tests
+    unsigned wnodes, wtris;   // wave-level executions of the two bodies (counted by the first active lane)
+};
+PT_DEV bool first_active_lane() {
+    const unsigned long long m = __ballot(1);
+    return (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1;
+}
+
+enum : int { kVisitLds = 0, kVisitGlobal = 1, kVisitFlat = 2 };      // Trav::node_step
+
+template <int MODE> struct StackOf { typedef unsigned type; };
+template <> struct StackOf<kNodesLds> { typedef unsigned short type; };
+
+// Closest hit over the whole scene; ties in t go to the lower encounter rank (the triangle the
+// reference's traversal, prog.cl:113-184, meets first).
+// While-while traversal, one "round" at a time: every lane first descends through interior nodes
+// until it holds a leaf (or has finished), then all lanes holding leaves intersect them.  The
+// per-lane state survives between rounds so that a flat loop can hand a finished lane its next ray
+// while the others keep going (wf_intersect).
+//
+// Node references (`cur`, child slots, stack entries):
+//   kNodesGlobal / kNodesTreelet   as the host packs them: >= 0 interior index, < 0 leaf
+//                                  ~(first << 3 | count - 1), kDone finished; 32-bit stack entries
+//   kNodesLds                      re-encoded to 16 bits by stage_nodes(): < 0x7fff interior index,
+//                                  0x7fff finished, 0x8000 | (first << 3 | count - 1) leaf -- nothing
+//                                  to encode or decode on a push or pop; 16-bit stack entries
+template <int MODE>
+struct Trav {
+    typedef typename StackOf<MODE>::type StackT;
+    static constexpr bool kRef16 = MODE == kNodesLds;
+    static constexpr bool kDefer = MODE != kNodesLds;     // see node_step
+    static constexpr int kDone = kRef16 ? 0x7fff : 0x7fffffff;
+    f3 P, D, inv;
+    float best_t;
+    int best;      // packed triangle index of the closest hit so far, -1 none
+    char* tos;     // top of this lane's stack (entry 0 = sentinel kDone), as a byte address
+    int stride;    // bytes between entries
+    int cur;
+    int k;         // single-step schedules: next triangle of the current leaf
+    int pend;      // round(): a leaf met during the node phase and not yet intersected (0: none)
+    int onx, ony, onz;   // byte offset of the entry-plane pair of each axis inside a staged node; 8 / 24 / 40 = direction negative
+    f3 cn, cf;           // -(P * inv) widened down / up (entry / exit distance = fma(plane, inv, c))
+
+    PT_DEV static bool is_node(int c) { return kRef16 ? c < 0x7fff : (unsigned)c < 0x7fffffffu; }
+    PT_DEV static bool is_leaf(int c) { return kRef16 ? c > 0x7fff : c < 0; }
+    PT_DEV static int leaf_bits(int c) { return kRef16 ? (c & 0x7fff) : ~c; }
+
+    PT_DEV void begin(f3 P_, f3 D_, const LaneStack<StackT> stk) {
+        P = P_;
+        D = D_;
+        inv = mk(__builtin_amdgcn_rcpf(D_.x), __builtin_amdgcn_rcpf(D_.y), __builtin_amdgcn_rcpf(D_.z));
+        best_t = __builtin_inff();
+        best = -1;
+        tos = reinterpret_cast<char*>(stk.base);
+        stride = stk.stride * (int)sizeof(StackT);
+        *reinterpret_cast<StackT*>(tos) = (StackT)kDone;
+        cur = 0;        // the root is always an interior node
+        k = 0;
+        pend = 0;
+        onx = __float_as_int(inv.x) < 0 ? 8 : 0;
+        ony = __float_as_int(inv.y) < 0 ? 24 : 16;
+        onz = __float_as_int(inv.z) < 0 ? 40 : 32;
+        // Distance to a plane as ONE fma: plane * inv - P * inv.  The product P * inv is rounded
+        // (half an ulp of |P * inv|, which can dwarf the distance itself), so the entry constant
+        // is lowered and the exit constant raised by 4 such half-ulps: entry distances come out
+        // too small, exit distances too large, never the other way round.  inf - inf = NaN
+        // (direction component 0 or underflowing) is ignored by max3/min3: that slab counts as
+        // entered, which only costs work.  This needs the entry / exit plane of an axis to be picked
+        // by the SIGN of the direction (by address in LDS, by select for nodes from global memory):
+        // with min/max picking them a NaN would be replaced by the other plane's distance and cull
+        // real hits (tests/test_gpu_parity.py::test_closest_hit_adversarial_rays).
+        const float px = P.x * inv.x, py = P.y * inv.y, pz = P.z * inv.z;
+        const float k22 = 2.3841858e-07f;    // 2^-22
+        const float ex = __builtin_fabsf(px) * k22, ey = __builtin_fabsf(py) * k22, ez = __builtin_fabsf(pz) * k22;
+        cn = mk(-(px + ex), -(py + ey), -(pz + ez));
+        cf = mk(-(px - ex), -(py - ey), -(pz - ez));
+    }
+    PT_DEV void idle() { cur = kDone; }
+    PT_DEV bool done() const { return cur == kDone; }
+
+    // One interior-node visit: slab-test both children, descend into the nearer hit one, push the
+    // other.  The visit is ONE basic block with one stack round trip: the top of the stack is fetched
+    // together with the node (it is the next node if neither child is hit), and the far child is
+    // stored above the top unconditionally; only the stack pointer moves conditionally.
+    //
+    // KIND = kVisitLds: the node is read from the staged copy, whose box quads are swizzled to
+    // {L.lo, R.lo, L.hi, R.hi}: the entry / exit planes of both children are picked by ADDRESS from
+    // the sign of the ray direction -- 7 8-byte LDS reads, no select (v_min/v_max/v_cndmask are
+    // 4-cycle ops on gfx950, tools/micro/exec_ops.hip; the adds that form the addresses are 2-cycle
+    // ops).  kVisitGlobal / kVisitFlat: the node comes as four 16-byte loads {L.lo, L.hi, R.lo, R.hi}
+    // (narrow per-lane global loads cost per instruction and lane, not per byte: 7 of them ran at
+    // 0.74-0.80x, profiles/r01/r_*) and the planes are picked by 12 selects; kVisitFlat loads through a
+    // generic pointer that is the lane's LDS copy for nodes of the treelet and global memory below it.
+    //
+    // DEFER (nodes from global memory): when the nearer child is a leaf and no leaf is pending, the
+    // leaf is remembered and the descent goes on with the other child or the stack; round()
+    // intersects it after the node phase.  A lane then goes through about half as many node-phase /
+    // leaf-phase alternations, each of which the whole wave waits out -- at the price of 3 % more
+    // node visits (the pending leaf cannot prune yet).  Measured: L1/L2 node path +5..8 %, LDS node
+    // path +-0 (the 5 extra VALU instructions per visit cost what the saved alternations bring).
+    template <bool COUNT, bool DEFER, int KIND>
+    PT_DEV void node_step(const SceneView& sv, WorkCount* wc) {
+        const float kWiden = 1.0000005f;   // > 4 ulp: covers rcp + fma (begin() covers P * inv)
+        const int top = (int)*reinterpret_cast<const StackT*>(tos);
+        float ln, lf, rn, rf;
+        int li, ri;
+        if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; }
+        if (KIND == kVisitLds) {
+            const char* nb = reinterpret_cast<const char*>(sv.lds_nodes) + ((size_t)(unsigned)cur << 6);
+            const float2 ex = *reinterpret_cast<const float2*>(nb + onx), xx = *reinterpret_cast<const float2*>(nb + (onx ^ 8));
+            const float2 ey = *reinterpret_cast<const float2*>(nb + ony), xy = *reinterpret_cast<const float2*>(nb + (ony ^ 8));
+            const float2 ez = *reinterpret_cast<const float2*>(nb + onz), xz = *reinterpret_cast<const float2*>(nb + (onz ^ 8));
+            const int2 ch = *reinterpret_cast<const int2*>(nb + 48);
+            ln = fmaxf(fmaxf(fmaf_(ex.x, inv.x, cn.x), fmaf_(ey.x, inv.y, cn.y)), fmaf_(ez.x, inv.z, cn.z));
+            rn = fmaxf(fmaxf(fmaf_(ex.y, inv.x, cn.x), fmaf_(ey.y, inv.y, cn.y)), fmaf_(ez.y, inv.z, cn.z));
+            lf = fminf(fminf(fmaf_(xx.x, inv.x, cf.x), fmaf_(xy.x, inv.y, cf.y)), fmaf_(xz.x, inv.z, cf.z)) * kWiden;
+            rf = fminf(fminf(fmaf_(xx.y, inv.x, cf.x), fmaf_(xy.y, inv.y, cf.y)), fmaf_(xz.y, inv.z, cf.z)) * kWiden;
+            li = ch.x;
+            ri = ch.y;
+        } else {
+            // (unsigned 32-bit byte offsets: scalar base + vector offset addressing, no 64-bit address
+            // math; pt_add_triangles caps the scene so that they cannot wrap)
+            const unsigned off = (unsigned)cur << 6;
+            float4 qx, qy, qz, qr;
+            if (KIND == kVisitFlat) {
+                const char* nb = ((unsigned)cur < sv.treelet ? reinterpret_cast<const char*>(sv.lds_nodes) : reinterpret_cast<const char*>(sv.nodes)) + off;
+                qx = *reinterpret_cast<const float4*>(nb);
+                qy = *reinterpret_cast<const float4*>(nb + 16);
+                qz = *reinterpret_cast<const float4*>(nb + 32);
+                qr = *reinterpret_cast<const float4*>(nb + 48);
+            } else {
+                const char* nb = reinterpret_cast<const char*>(sv.nodes);
+                qx = *reinterpret_cast<const float4*>(nb + off);
+                qy = *reinterpret_cast<const float4*>(nb + (off + 16u));
+                qz = *reinterpret_cast<const float4*>(nb + (off + 32u));
+                qr = *reinterpret_cast<const float4*>(nb + (off + 48u));
+            }
+#if PT_GLOBAL_SLAB_FMA
+            const bool sx = onx == 8, sy = ony == 24, sz = onz == 40;
+            const float lnx = sx ? qx.y : qx.x, lfx = sx ? qx.x : qx.y, rnx = sx ? qx.w : qx.z, rfx = sx ? qx.z : qx.w;
+            const float lny = sy ? qy.y : qy.x, lfy = sy ? qy.x : qy.y, rny = sy ? qy.w : qy.z, rfy = sy ? qy.z : qy.w;
+            const float lnz = sz ? qz.y : qz.x, lfz = sz ? qz.x : qz.y, rnz = sz ? qz.w : qz.z, rfz = sz ? qz.z : qz.w;
+            ln = fmaxf(fmaxf(fmaf_(lnx, inv.x, cn.x), fmaf_(lny, inv.y, cn.y)), fmaf_(lnz, inv.z, cn.z));
+            rn = fmaxf(fmaxf(fmaf_(rnx, inv.x, cn.x), fmaf_(rny, inv.y, cn.y)), fmaf_(rnz, inv.z, cn.z));
+            lf = fminf(fminf(fmaf_(lfx, inv.x, cf.x), fmaf_(lfy, inv.y, cf.y)), fmaf_(lfz, inv.z, cf.z)) * kWiden;
+            rf = fminf(fminf(fmaf_(rfx, inv.x, cf.x), fmaf_(rfy, inv.y, cf.y)), fmaf_(rfz, inv.z, cf.z)) * kWiden;
+#else
+            // (plane - P) * inv with min/max picking the planes: ~2 ulp per distance, covered by the
+            // 4-ulp widening (a NaN here is replaced by the other plane's finite distance, which is safe
+            // only in this subtract-then-multiply form)
+            const float lx0 = (qx.x - P.x) * inv.x, lx1 = (qx.y - P.x) * inv.x;
+            const float rx0 = (qx.z - P.x) * inv.x, rx1 = (qx.w - P.x) * inv.x;
+            const float ly0 = (qy.x - P.y) * inv.y, ly1 = (qy.y - P.y) * inv.y;
+            const float ry0 = (qy.z - P.y) * inv.y, ry1 = (qy.w - P.y) * inv.y;
+            const float lz0 = (qz.x - P.z) * inv.z, lz1 = (qz.y - P.z) * inv.z;
+            const float rz0 = (qz.z - P.z) * inv.z, rz1 = (qz.w - P.z) * inv.z;
+            ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
+            lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1)) * kWiden;
+            rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
+            rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1)) * kWiden;
+#endif
+            li = __float_as_int(qr.x);
+            ri = __float_as_int(qr.y);
+        }
+        const float lim = best_t * kWiden;
+        const bool hl = (lf >= ln) && (lf >= 0.0f) && (ln <= lim);
+        const bool hr = (rf >= rn) && (rf >= 0.0f) && (rn <= lim);
+        const bool lfirst = ln <= rn;      // (its own statement: inside the expression below it comes back as a branch)
+        const bool take_left = hl && (!hr || lfirst);
+        const bool both = hl && hr, none = !(hl || hr);
+        const int other = take_left ? ri : li;
+        *reinterpret_cast<StackT*>(tos + stride) = (StackT)other;
+        const int next = take_left ? li : ri;
+        if (DEFER) {
+            const bool cap = !none && is_leaf(next) && pend == 0;
+            pend = cap ? next : pend;
+            const bool usetop = none || (cap && !both);
+            cur = usetop ? top : (cap ? other : next);
+            tos += (both && !cap) ? stride : (usetop ? -stride : 0);
+        } else {
+            cur = none ? top : next;
+            tos += both ? stride : (none ? -stride : 0);
+        }
+    }
+
+    // one visit of whichever kind the current node needs (flat single-step loops; no deferred leaf)
+    template <bool COUNT>
+    PT_DEV void node_step_any(const SceneView& sv, WorkCount* wc) {
+        node_step<COUNT, false, MODE == kNodesLds ? kVisitLds : MODE == kNodesGlobal ? kVisitGlobal : kVisitFlat>(sv, wc);
+    }
+
+    // exact test of packed triangle ti against the ray, keeping the closest (ties: lower rank)
+    template <bool COUNT>
+    PT_DEV void tri_step(const SceneView& sv, int ti, WorkCount* wc) {
+        const char* tb = reinterpret_cast<const char*>(sv.tris);
+        const unsigned off = (unsigned)ti * 48u;
+        const float4 a = *reinterpret_cast<const float4*>(tb + off), b = *reinterpret_cast<const float4*>(tb + (off + 16u)), c = *reinterpret_cast<const float4*>(tb + (off + 32u));
+        if (COUNT) { wc->tris++; if (first_active_lane()) wc->wtris++; }
+        const float t = tri_test<MODE == kNodesLds>(a, b, c, P, D, best_t * 1.000002f);
+        if (t > 0.0f) {
+            bool better = t < best_t;
+            if (t == best_t && best >= 0) better = sv.meta[ti].rank < sv.meta[best].rank;
+            if (better) { best_t = t; best = ti; }
+        }
+    }
+
+    PT_DEV void pop() {
+        cur = (int)*reinterpret_cast<const StackT*>(tos);
+        tos -= stride;
+    }
+
+    template <bool COUNT>
+    PT_DEV void round(const SceneView& sv, WorkCount* wc) {
+        if (MODE == kNodesLds) {
+            while (is_node(cur)) node_step<COUNT, false, kVisitLds>(sv, wc);
+        } else if (MODE == kNodesGlobal) {
+            while (is_node(cur)) node_step<COUNT, true, kVisitGlobal>(sv, wc);
+        } else {
+            while (is_node(cur)) node_step<COUNT, true, kVisitFlat>(sv, wc);
+        }
+        if (kDefer && pend != 0) {            // met first, so nearer: intersect it first
+            const int v = leaf_bits(pend);
+            const int first = v >> 3, count = (v & 7) + 1;
+            for (int j = 0; j < count; ++j) tri_step<COUNT>(sv, first + j, wc);
+            pend = 0;
+        }
+        while (is_leaf(cur)) {
+            const int popped = (int)*reinterpret_cast<const StackT*>(tos);     // in flight during the triangle tests
+            const int v = leaf_bits(cur);
+            const int first = v >> 3, count = (v & 7) + 1;
+            for (int j = 0; j < count; ++j) tri_step<COUNT>(sv, first + j, wc);
+            cur = popped;
+            tos -= stride;
+        }
+    }
+
+    // one triangle of the current leaf (single-step schedules)
+    template <bool COUNT>
+    PT_DEV void leaf_step(const SceneView& sv, WorkCount* wc) {
+        const int v = leaf_bits(cur);
+        const int first = v >> 3, count = (v & 7) + 1;
+        tri_step<COUNT>(sv, first + k, wc);
+        if (++k >= count) {
+            k = 0;
+            pop();
+        }
+    }
+};
+
+template <int MODE, bool COUNT>
+PT_DEV int closest_hit(const SceneView& sv, f3 P, f3 D, const LaneStack<typename StackOf<MODE>::type> stk, float* t_out, WorkCount* wc) {
+    Trav<MODE> tr;
+    tr.begin(P, D, stk);
+    while (!tr.done()) tr.template round<COUNT>(sv, wc);
+    *t_out = tr.best_t;
+    return tr.best;
+}
+
+// ---------------------------------------------------------------------------- BSDF sampling
+struct RayPD {
+    f3 P, D;
+};
+
+// prog.cl:186-218
+PT_DEV RayPD new_ray_diffuse(f3 hp, f3 N, float rnd1, float rnd2) {
+    const float E = 0.001f;
+    const bool yaxis = __builtin_fabsf(N.x) <= E && __builtin_fabsf(N.z) <= E;
+    const float other = yaxis ? N.y : N.x;
+    const float rl = 1.0f / __builtin_sqrtf(fmaf_(N.z, N.z, other * other));
+    const f3 Z = yaxis ? mk(0.0f, -N.z * rl, N.y * rl) : mk(-N.z * rl, 0.0f, N.x * rl);
+    const f3 X = cross3(N, Z);
+    const float r = __builtin_sqrtf(rnd1);
+    const float theta = (float)(6.283185307179586 * (double)rnd2);
+    float sn, cs;
+    spec_sincos(theta, &sn, &cs);
+    const float x = r * cs, y = r * sn, z = __builtin_sqrtf(1.0f - rnd1);
+    f3 d = X * x;
+    d = madd(N, z, d);
+    d = madd(Z, y, d);
+    RayPD o;
+    o.P = madd(N, E, hp);
+    o.D = normalize3(d);
+    return o;
+}
+
+// prog.cl:219-222
+PT_DEV f3 fresnel(f3 F0, f3 N, f3 D) {
+    const float cosa = __builtin_fabsf(dot3(N, D));
+    const float p5 = spec_pow5(1.0f - cosa);
+    return mk(fmaf_(1.0f - F0.x, p5, F0.x), fmaf_(1.0f - F0.y, p5, F0.y), fmaf_(1.0f - F0.z, p5, F0.z));
+}
+
+// prog.cl:223-227
+PT_DEV RayPD new_ray_specular(f3 hp, f3 N, f3 oldD) {
+    const float cosa = dot3(N, oldD);
+    RayPD o;
+    o.D = normalize3(oldD - (N * cosa) * 2.0f);
+    o.P = madd(N, 0.001f, hp);
+    return o;
+}
+
+// prog.cl:228-245; *flipped = the path crossed the interface (in = !in)
+PT_DEV RayPD new_ray_refractive(f3 hp, f3 N, f3 F0, float n, f3 oldD, bool in, float rnd, bool* flipped) {
+    if (in) n = 1.0f / n;
+    const float cosa = dot3(-oldD, N);
+    const float disc = 1.0f - (fmaf_(-cosa, cosa, 1.0f) / n) / n;
+    const f3 F = fresnel(F0, N, oldD);
+    const float prob = ((F.x + F.y) + F.z) / 3.0f;
+    const bool refr = disc > 0.0f && rnd > prob;
+    *flipped = refr;
+    // both candidate directions before normalisation; one normalize serves either branch
+    const f3 dn = mk(oldD.x / n, oldD.y / n, oldD.z / n);
+    const f3 dr = madd(N, cosa / n - __builtin_sqrtf(disc), dn);
+    const f3 dm = oldD - (N * dot3(N, oldD)) * 2.0f;
+    RayPD o;
+    o.D = normalize3(refr ? dr : dm);
+    o.P = madd(N, refr ? -0.001f : 0.001f, hp);
+    return o;
+}
+
+// ---------------------------------------------------------------------------- path state + shading
+// The path state of prog.cl:307-316 lives in plain local variables (registers), passed by
+// reference: P, D, the four factors, the colour, the LCG state and the inside-glass flag.
+#define PT_PATH_ARGS f3 &rP, f3 &rD, f3 &fL, f3 &fB, f3 &fS, f3 &fR, f3 &color, int &seed, bool &inside
+
+// one iteration body of prog.cl:317-366 for a ray that hit packed triangle `ti` at `t`
+PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, const TriMeta* meta, int ti, float t) {
+    const float4 c = tris[ti * 3 + 2];
+    f3 N = mk(c.y, c.z, c.w);
+    const f3 hp = madd(rD, t, rP);
+    const pt_material* __restrict__ m = &p.mats[meta[ti].mati];
+    const int type = m->type;
+    if (p.iterations == 1) color = ldf3(m->kd) + ldf3(m->emission);         // prog.cl:323-325
+    if (dot3(rD, N) > 0.0f) N = -N;                                         // prog.cl:326-328
+    if (type == 0 || type == 3) {
+        // diffuse (prog.cl:329-340) and emitter (prog.cl:358-366) both continue with a cosine-
+        // sampled ray drawn from two LCG values; the emitter's cosine uses the OLD direction.
+        const float inten = max0(dot3(-rD, N));
+        const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+        const RayPD nr = new_ray_diffuse(hp, N, rnd1, rnd2);
+        if (type == 0) {
+            const float idiff = max0(dot3(nr.D, N));
+            fL = fL * (ldf3(m->kd) * idiff);
+            const f3 view = normalize3(ldf3(p.cam.eye) - hp);
+            const f3 halfway = normalize3(view + nr.D);
+            const float ispec = max0(dot3(N, halfway));
+            // m->_pad = 1: ks is exactly 0 and shininess is finite >= 0, so ks * pow(...) is +0 whatever the
+            // (finite) power is -- skip the double-precision pow (set by pt_upload_materials)
+            const float pw = m->_pad ? 1.0f : spec_pow(ispec, m->shininess);
+            fB = fB * (ldf3(m->ks) * pw);
+        } else {
+            const f3 e = ((ldf3(m->emission) * (fL + fB)) * fS) * fR;
+            color = madd(e, inten, color);
+        }
+        rP = nr.P;
+        rD = nr.D;
+    } else if (type == 1 || type == 2) {
+        // mirror (prog.cl:341-345) and dielectric (prog.cl:346-357, 228-245) share the Fresnel
+        // term and the mirror direction; the dielectric may pick the refracted direction instead.
+        const f3 oldD = rD;
+        const f3 F0 = ldf3(m->F0);
+        const f3 F = fresnel(F0, N, oldD);
+        f3 dsel = oldD - (N * dot3(N, oldD)) * 2.0f;
+        bool refr = false;
+        if (type == 2) {
+            float n = m->n;
+            if (inside) n = 1.0f / n;
+            const float rnd = lcg_rand(seed);
+            const float cosa = dot3(-oldD, N);
+            const float disc = 1.0f - (fmaf_(-cosa, cosa, 1.0f) / n) / n;
+            const float prob = ((F.x + F.y) + F.z) / 3.0f;
+            refr = disc > 0.0f && rnd > prob;
+            if (refr) {
+                const f3 dn = mk(oldD.x / n, oldD.y / n, oldD.z / n);
+                dsel = madd(N, cosa / n - __builtin_sqrtf(disc), dn);
+                const float k = 1.0f / (1.0f - prob);
+                fR = (fR * mk(1.0f - F.x, 1.0f - F.y, 1.0f - F.z)) * k;
+                inside = !inside;
+            } else {
+                const float k = 1.0f / prob;
+                fR = (fR * F) * k;
+            }
+        } else {
+            fS = fS * F;
+        }
+        rD = normalize3(dsel);
+        rP = madd(N, refr ? -0.001f : 0.001f, hp);
+    }
+    // any other type: the ray is left unchanged and the loop hits the same surface again
+}
+
+PT_DEV f3 running_mean(f3 acc, f3 color, int s) {   // prog.cl:379
+    const float cs = (float)s, cs1 = (float)(s + 1);
+    return mk(fmaf_(acc.x, cs, color.x) / cs1, fmaf_(acc.y, cs, color.y) / cs1, fmaf_(acc.z, cs, color.z) / cs1);
+}
+
+// ---------------------------------------------------------------------------- LDS staging
+extern __shared__ __attribute__((aligned(16))) unsigned char pt_lds_raw[];
+
+// Nodes staged in LDS are re-laid out on the way in: the three box quads {L.lo, L.hi, R.lo, R.hi}
+// become {L.lo, R.lo, L.hi, R.hi}, so that one 8-byte read at (quad + 0 | 8) returns the entry
+// (or exit) planes of BOTH children for a ray whose direction sign on that axis is known
+// (Trav::node_step, kVisitLds), and the child slots of the fourth quad are re-encoded to the 16-bit
+// reference form.  The treelet of a large tree is staged verbatim (kVisitFlat reads both copies alike).
+PT_DEV float stage_ref(float slot) {
+    const int r = __float_as_int(slot);
+    return __int_as_float(r < 0 ? (0x8000 | ~r) : r);
+}
+template <int MODE>
+PT_DEV void stage_nodes(const RenderParams& p, float4* lds_nodes) {
+    const int nn = (MODE == kNodesLds ? p.n_nodes : p.treelet_nodes) * 4;
+    for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+        const float4 q = p.nodes[i];
+        if (MODE != kNodesLds) lds_nodes[i] = q;
+        else if ((i & 3) != 3) lds_nodes[i] = make_float4(q.x, q.z, q.y, q.w);
+        else lds_nodes[i] = make_float4(stage_ref(q.x), stage_ref(q.y), q.z, q.w);
+    }
+}
+
+// LDS layout of every traversal kernel: [per-lane stacks: stack_entries x BLOCK entries][staged nodes]
+template <int MODE, int BLOCK>
+PT_DEV size_t traversal_stack_bytes_dev(const RenderParams& p) {
+    return ((size_t)p.stack_entries * sizeof(typename StackOf<MODE>::type) * BLOCK + 15) & ~(size_t)15;
+}
+template <int MODE, int BLOCK>
+PT_DEV size_t traversal_lds_bytes_dev(const RenderParams& p) {      // == traversal_lds_bytes() on the host
+    return traversal_stack_bytes_dev<MODE, BLOCK>(p) + (MODE == kNodesLds ? (size_t)p.n_nodes * 64 : MODE == kNodesTreelet ? (size_t)p.treelet_nodes * 64 : 0);
+}
+template <int MODE, int BLOCK>
+PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<typename StackOf<MODE>::type>* stk) {
+    typedef typename StackOf<MODE>::type StackT;
+    stk->base = reinterpret_cast<StackT*>(pt_lds_raw) + threadIdx.x;          // [entry][lane]
+    stk->stride = BLOCK;
+    sv->nodes = p.nodes;
+    sv->tris = p.tris;
+    sv->meta = p.meta;
+    sv->treelet = (unsigned)p.treelet_nodes;
+    sv->lds_nodes = nullptr;
+    if (MODE != kNodesGlobal) {
+        float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + traversal_stack_bytes_dev<MODE, BLOCK>(p));
+        stage_nodes<MODE>(p, lds_nodes);
+        __syncthreads();
+        sv->lds_nodes = lds_nodes;
+    }
+}
+
+// statistics live in kStatRows rows of 8 counters; a block adds to the row picked by its index, so
+// no single address sees more than a few dozen atomics per launch (one address saturates at
+// ~88 atomics/us on MI355X, which cost a 32k-wave launch ~0.4 ms when every wave hit one word)
+PT_DEV void stat_add(const RenderParams& p, int slot, unsigned long long v) {
+    atomicAdd(&p.stats[(size_t)((blockIdx.x + blockIdx.y * 37u) % kStatRows) * 8 + slot], v);
+}
+
+PT_DEV unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+}  // namespace ptamd

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <queue>
 
 using namespace ptamd;
 
@@ -41,6 +42,12 @@ struct pt_context {
     int32_t rank = 0, world = 1, rows_per_block = 8;
     int32_t local_rows = 0;
     int64_t npix = 0;  // local pixels
+    int64_t slab_pix = 0;  // max over ranks of the local pixel count: what every rank contributes to the all-gather
+
+    // ---- frame assembly (pt_comm.hip)
+    void* comm = nullptr;          // ncclComm_t
+    float4* d_gathered = nullptr;  // world x slab_pix
+    float4* d_frame = nullptr;     // W x H
 
     // ---- authoring state (Scene members, main.cpp:365-372)
     std::vector<pt_triangle> tris;  // add order
@@ -80,12 +87,12 @@ struct pt_context {
 
     // ---- options
     int variant = 0;
-    int block = 256;
-    int lds_scene = 2;   // 2: stage the BVH nodes in LDS when they fit next to two 512-thread blocks per CU (+5 %
-                         // measured); 1: nodes and packets (costs occupancy and needs a fat-leaf tree: slower); 0: off
+    int lds_scene = 2;   // 2: stage BVH nodes in LDS -- the whole tree when it fits next to two 512-thread blocks per
+                         // CU, otherwise its top (`treelet`); 0: every node through L1/L2
+    int treelet = -1;    // nodes of a large tree to stage in LDS: -1 what fits one 1,024-thread block per CU, 0 none, n
+    int treelet_nodes = 0;   // decided at upload: nodes [0, treelet_nodes) are the re-indexed top of the tree
     int timing = 0;
     int count_work = 0;
-    int traversal = 0;    // 0 while-while, 1 voting
     int bvh_on_device = 0;
     double bvh_build_ms = 0.0;
     int cu_count = 256;
@@ -95,12 +102,9 @@ struct pt_context {
     int chunk_spp = -1;   // persistent megakernel work items: > 0 (pass, tile) items of that many samples, 0 whole
                           // tiles, -1 automatic (4 when the context has clearly more tiles than resident waves)
     int sah_visit_cost = 10;   // tenths of a triangle test (option sah_visit_cost)
-    int pixel_map = 0;    // 0 tiles of 8x8 per wave, 1 strided (balances waves; for ranks with few waves)
-    int debug_lds_pad = 0; // extra LDS bytes per block of the timed debug launches (limits occupancy)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
-    int min_waves = 4;    // k_render at 128 VGPRs (4 waves/SIMD) measured fastest
-    int bvh_policy = 0;   // 0 auto (SAH termination; LDS fit when lds_scene is on), 1 SAH termination, 2 leaves of <= 4, 3 leaves of <= 8
+    int bvh_policy = 0;   // 0/1 host SAH with SAH leaf termination, 2 leaves of <= 4, 3 leaves of <= 8, 4 device LBVH
 
     // ---- statistics
     std::vector<EventPair> events;
@@ -123,7 +127,14 @@ int fail(pt_context* ctx, int code, const std::string& msg) {
 }  // namespace
 
 namespace ptamd {
-int fail_ctx(pt_context* ctx, int code, const std::string& msg) { return fail(ctx, code, msg); }   // for pt_obj.cpp
+int fail_ctx(pt_context* ctx, int code, const std::string& msg) { return fail(ctx, code, msg); }   // for pt_obj.cpp, pt_image.cpp
+// pt_comm.hip
+hipError_t launch_deinterleave(const float4* gathered, float4* frame, int W, int H, int world, int rb, long long slab_stride, hipStream_t stream);
+void gather_source_index(int W, int H, int world, int rb, long long slab_stride, int64_t* out);
+int comm_unique_id(void* id128, std::string* err);
+int comm_init(const void* id128, int rank, int world, void** comm_out, std::string* err);
+void comm_destroy(void* comm);
+int comm_all_gather(void* comm, const void* send, void* recv, size_t floats_per_rank, hipStream_t stream, std::string* err);
 }
 
 namespace {
@@ -395,26 +406,10 @@ int build_and_pack(pt_context* ctx) {
         p.tri = (int32_t)i;
         prims.push_back(p);
     }
-    // Attempts, best traversal quality first; a later (fatter-leaved, smaller) tree is taken only
-    // if it makes the whole scene fit the LDS of one CU next to the traversal stacks.
-    const size_t lds_budget = 160 * 1024;
-    auto footprint = [&](const BvhBuilder& b) {
-        int entries = std::min(kStackEntries, ((b.max_depth_seen + 4) + 1) & ~1);
-        return sizeof(Node64) * b.nodes.size() + sizeof(TriPacket) * b.order.size() + (size_t)entries * 4 * 256;
-    };
     BvhBuilder bld;
     int rc = ctx->bvh_policy <= 1 ? build_attempt(ctx, bld, prims, 4, false)
                                   : build_attempt(ctx, bld, prims, ctx->bvh_policy == 2 ? 4 : 8, true);
     if (rc != PT_OK) return rc;
-    if (ctx->bvh_policy == 0 && ctx->lds_scene == 1 && footprint(bld) > lds_budget && sizeof(TriPacket) * prims.size() < lds_budget) {
-        const int tries[2][2] = {{4, 1}, {8, 1}};
-        for (auto& t : tries) {
-            BvhBuilder alt;
-            rc = build_attempt(ctx, alt, prims, t[0], t[1] != 0);
-            if (rc != PT_OK) return rc;
-            if (footprint(alt) <= lds_budget) { bld = std::move(alt); break; }
-        }
-    }
     if (bld.max_depth_seen > kMaxDepth) return fail(ctx, PT_ESCENE, "internal: BVH deeper than the traversal stack");
     ctx->bvh_depth = bld.max_depth_seen;
     ctx->nodes.swap(bld.nodes);
@@ -466,6 +461,72 @@ void compute_cost_boxes_impl(pt_context* ctx) {
     }
 }
 
+// Stack entries a traversal of this tree needs: sentinel + one far child per level + the slot above the top
+// that Trav::node_step writes unconditionally (+ 2 spare), rounded to even.
+int stack_entries_for(int bvh_depth) { return std::min(kStackEntries, ((bvh_depth + 4) + 1) & ~1); }
+
+constexpr size_t kLdsPerCu = 160 * 1024;
+constexpr size_t kLdsSlack = 8 * 1024;     // wf_intersect's compaction arrays live next to the stacks and nodes
+
+// Does the whole tree fit next to two 512-thread workgroups per CU (kNodesLds: 16-bit references)?
+bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int bvh_depth) {
+    const bool s16 = n_nodes <= 32767 && n_tris <= 4096;
+    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(bvh_depth) * 2 * 512 + 32 <= kLdsPerCu / 2;
+}
+
+// Treelet: when the tree is too large for LDS, the T nodes with the largest boxes --
+// the ones a ray is most likely to visit; a child's box lies inside its parent's, so they form a connected
+// top of the tree -- are renumbered to [0, T) and every workgroup stages exactly those.  T is what one
+// 1,024-thread workgroup per CU has left next to its 32-bit stacks.  The rest keeps its depth-first order.
+// Returns T (0: no treelet).
+int reindex_treelet(std::vector<Node64>& nodes, int bvh_depth, int want) {
+    const size_t n = nodes.size();
+    const size_t stacks = (size_t)stack_entries_for(bvh_depth) * 4 * 1024;
+    if (stacks + kLdsSlack + 64 * sizeof(Node64) > kLdsPerCu) return 0;
+    size_t cap = (kLdsPerCu - kLdsSlack - stacks) / sizeof(Node64);
+    if (want > 0) cap = std::min(cap, (size_t)want);
+    const size_t T = std::min(cap, n);
+    if (T < 2) return 0;
+    auto area = [&](int32_t i) {
+        const Node64& nd = nodes[(size_t)i];
+        float d[3];
+        for (int a = 0; a < 3; ++a) d[a] = std::max(nd.q[a][1], nd.q[a][3]) - std::min(nd.q[a][0], nd.q[a][2]);
+        const float h = d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+        return std::isfinite(h) ? h : std::numeric_limits<float>::infinity();
+    };
+    typedef std::pair<float, int32_t> Item;        // (area, -index): ties go to the lower index
+    std::priority_queue<Item> pq;
+    std::vector<int32_t> newidx(n, -1);
+    pq.push(Item(area(0), 0));
+    int32_t next = 0;
+    while (!pq.empty() && (size_t)next < T) {
+        const int32_t i = -pq.top().second;
+        pq.pop();
+        newidx[(size_t)i] = next++;
+        const Node64& nd = nodes[(size_t)i];
+        if (nd.left >= 0) pq.push(Item(area(nd.left), -nd.left));
+        if (nd.right >= 0) pq.push(Item(area(nd.right), -nd.right));
+    }
+    const int32_t t_final = next;
+    for (size_t i = 0; i < n; ++i)
+        if (newidx[i] < 0) newidx[i] = next++;
+    std::vector<Node64> out(n);
+    for (size_t i = 0; i < n; ++i) {
+        Node64 nd = nodes[i];
+        if (nd.left >= 0) nd.left = newidx[(size_t)nd.left];
+        if (nd.right >= 0) nd.right = newidx[(size_t)nd.right];
+        out[(size_t)newidx[i]] = nd;
+    }
+    nodes.swap(out);
+    return t_final;
+}
+
+void plan_node_placement(pt_context* ctx) {
+    ctx->treelet_nodes = 0;
+    if (ctx->treelet == 0 || whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->bvh_depth)) return;
+    ctx->treelet_nodes = reindex_treelet(ctx->nodes, ctx->bvh_depth, ctx->treelet);
+}
+
 template <class T>
 int upload_vec(pt_context* ctx, T** dptr, const void* src, size_t bytes) {
     if (*dptr) { PT_HIP(ctx, hipFree(*dptr)); *dptr = nullptr; }
@@ -507,8 +568,18 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->rows_per_block = ctx->rows_per_block;
     p->n_nodes = (int32_t)ctx->nodes.size();
     p->n_tris = (int32_t)ctx->orig.size();
-    p->stack_entries = std::min(kStackEntries, ((ctx->bvh_depth + 4) + 1) & ~1);   // sentinel + far children + the slot above the top (Trav::node_step)
-    p->pixel_map = ctx->pixel_map;
+    p->stack_entries = stack_entries_for(ctx->bvh_depth);
+    // where the traversal reads nodes from: the whole tree staged in LDS, its re-indexed top, or L1/L2 only
+    p->node_mode = kNodesGlobal;
+    p->treelet_nodes = 0;
+    if (ctx->lds_scene) {
+        if (whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->bvh_depth)) {
+            p->node_mode = kNodesLds;
+        } else if (ctx->treelet_nodes > 0) {
+            p->node_mode = kNodesTreelet;
+            p->treelet_nodes = ctx->treelet_nodes;
+        }
+    }
     p->tile_counter = nullptr;
     p->chunk_spp = 0;
     p->tile_done = nullptr;
@@ -641,6 +712,7 @@ int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int
     ctx->rows_per_block = rows_per_block;
     ctx->local_rows = count_local_rows(height, rank, world, rows_per_block);
     ctx->npix = (int64_t)ctx->local_rows * width;
+    for (int32_t r = 0; r < world; ++r) ctx->slab_pix = std::max(ctx->slab_pix, (int64_t)count_local_rows(height, r, world, rows_per_block) * width);
     ctx->device = device;
     if (device < 0) {  // host-only context: authoring + BVH build + debug getters, nothing renders
         std::snprintf(ctx->info, sizeof ctx->info, "host-only context (no device)");
@@ -671,13 +743,14 @@ int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int
     }
     ctx->has_device = true;
     const size_t np = (size_t)std::max<int64_t>(ctx->npix, 1);
+    const size_t nslab = (size_t)std::max<int64_t>(ctx->slab_pix, 1);      // colors is this rank's slab of the all-gather
     if ((e = hipMalloc((void**)&ctx->d_rays, sizeof(pt_ray) * np)) != hipSuccess) return bail("hipMalloc(rays)", e);      // main.cpp:508
     if ((e = hipMalloc((void**)&ctx->d_rnds, sizeof(int32_t) * np)) != hipSuccess) return bail("hipMalloc(rnds)", e);     // main.cpp:509
-    if ((e = hipMalloc((void**)&ctx->d_colors, sizeof(float4) * np)) != hipSuccess) return bail("hipMalloc(colors)", e);  // main.cpp:520
+    if ((e = hipMalloc((void**)&ctx->d_colors, sizeof(float4) * nslab)) != hipSuccess) return bail("hipMalloc(colors)", e);  // main.cpp:520
     if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * 8 * kStatRows)) != hipSuccess) return bail("hipMalloc(stats)", e);
     if ((e = hipMalloc((void**)&ctx->d_tile_counter, 64)) != hipSuccess) return bail("hipMalloc(tile counter)", e);
     if ((e = hipMemset(ctx->d_rays, 0, sizeof(pt_ray) * np)) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipMemset(ctx->d_colors, 0, sizeof(float4) * np)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemset(ctx->d_colors, 0, sizeof(float4) * nslab)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8 * kStatRows)) != hipSuccess) return bail("hipMemset", e);
     int rc = pt_seed_default(ctx);                                                                                    // main.cpp:522-527
     if (rc != PT_OK) {
@@ -711,6 +784,9 @@ void pt_destroy(pt_context* ctx) {
         if (ctx->d_wf_state) (void)hipFree(ctx->d_wf_state);
         if (ctx->d_wf_queues) (void)hipFree(ctx->d_wf_queues);
         if (ctx->d_wf_counters) (void)hipFree(ctx->d_wf_counters);
+        if (ctx->comm) comm_destroy(ctx->comm);
+        if (ctx->d_gathered) (void)hipFree(ctx->d_gathered);
+        if (ctx->d_frame) (void)hipFree(ctx->d_frame);
         if (ctx->own_rnds && ctx->d_rnds) (void)hipFree(ctx->d_rnds);
         if (ctx->own_colors && ctx->d_colors) (void)hipFree(ctx->d_colors);
     }
@@ -737,7 +813,8 @@ int pt_add_triangle(pt_context* ctx, const pt_triangle* t) { return pt_add_trian
 
 int pt_add_triangles(pt_context* ctx, const pt_triangle* t, int64_t n) {
     if (!ctx || (!t && n) || n < 0) return PT_EINVAL;
-    if ((int64_t)ctx->tris.size() + n > ((int64_t)1 << 27)) return fail(ctx, PT_EINVAL, "more than 2^27 triangles");
+    if ((int64_t)ctx->tris.size() + n > kMaxTriangles)      // checked before anything is read: 32-bit device offsets (pt_internal.hpp)
+        return fail(ctx, PT_EINVAL, "more than 2^26 triangles");
     ctx->tris.insert(ctx->tris.end(), t, t + n);
     ctx->tris_uploaded = false;
     return PT_OK;
@@ -794,6 +871,8 @@ static int build_on_device(pt_context* ctx, bool* done) {
     PT_HIP(ctx, hipMemcpy(ctx->orig.data(), r.d_orig, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(r.d_orig);
     ctx->bvh_depth = r.depth + 1;
+    plan_node_placement(ctx);
+    if (ctx->treelet_nodes > 0) PT_HIP(ctx, hipMemcpy(ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size(), hipMemcpyHostToDevice));
     *done = true;
     return PT_OK;
 }
@@ -819,8 +898,9 @@ int pt_upload_triangles(pt_context* ctx) {
     }
     ctx->bvh_on_device = 0;
     int rc = build_and_pack(ctx);
-    ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rc != PT_OK) return rc;
+    plan_node_placement(ctx);
+    ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (ctx->has_device) {
         PT_HIP(ctx, hipSetDevice(ctx->device));
         if ((rc = upload_vec(ctx, &ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size())) != PT_OK) return rc;
@@ -868,32 +948,14 @@ int pt_upload_seeds(pt_context* ctx, const int32_t* seeds, int64_t n) {
     return seed_upload(ctx, seeds);
 }
 
-static int launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc, int block) {
-    lc->block = block;
-    lc->lds_bytes = mega_lds_bytes(p, block);
+static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc) {
+    lc->block = traversal_block(p.node_mode);
+    lc->lds_bytes = traversal_lds_bytes(p, lc->block);
     lc->count_work = ctx->count_work != 0;
-    lc->min_waves = ctx->min_waves;
-    lc->traversal = ctx->traversal;
-    // resident workgroups: 256 CUs x (2048 threads at 4 waves/SIMD ... the launcher's MINW decides; use
-    // the LDS/VGPR-limited count of the default configurations: 4 x 256-thread or 2 x 512-thread blocks)
-    lc->persistent_blocks = ctx->cu_count * std::max(1, 1024 / block);
+    // resident workgroups at 4 waves per SIMD: 4 x 256 threads (nodes through L1/L2), 2 x 512 (whole tree in
+    // LDS), 1 x 1024 (treelet) per CU
+    lc->persistent_blocks = ctx->cu_count * std::max(1, 1024 / lc->block);
     ctx->last_lds_bytes = lc->lds_bytes;
-    return PT_OK;
-}
-
-static void decide_lds_scene(const pt_context* ctx, RenderParams* p, int* block_out) {
-    *block_out = ctx->block;
-    if (ctx->lds_scene == 2) {      // nodes only: needs the 16-bit stack encoding and two 512-thread blocks per CU
-        const bool s16 = ctx->nodes.size() <= 32767 && ctx->orig.size() <= 4096;
-        const size_t need = sizeof(Node64) * ctx->nodes.size() + (size_t)p->stack_entries * 2 * 512 + 32;
-        p->lds_scene = (s16 && need <= 80 * 1024) ? 2 : 0;
-        if (p->lds_scene) *block_out = 512;
-        return;
-    }
-    size_t scene = sizeof(Node64) * ctx->nodes.size() + sizeof(TriPacket) * ctx->orig.size();
-    const bool s16 = ctx->nodes.size() <= 32767 && ctx->orig.size() <= 4096;
-    size_t stack = (size_t)p->stack_entries * (s16 ? 2 : 4) * (size_t)ctx->block + 16;
-    p->lds_scene = (ctx->lds_scene && scene + stack <= (size_t)mega_max_lds_scene_bytes()) ? 1 : 0;
 }
 
 int pt_generate_rays(pt_context* ctx, const pt_camera* cam) {
@@ -903,9 +965,7 @@ int pt_generate_rays(pt_context* ctx, const pt_camera* cam) {
     PT_HIP(ctx, hipSetDevice(ctx->device));
     RenderParams p;
     fill_params(ctx, cam, &p);
-    LaunchConfig lc;
-    lc.block = 256;
-    PT_HIP(ctx, launch_gen_ray(p, lc, ctx->stream));
+    PT_HIP(ctx, launch_gen_ray(p, ctx->stream));
     return PT_OK;
 }
 
@@ -920,10 +980,8 @@ int pt_trace_rays(pt_context* ctx, const pt_camera* cam, int32_t iterations, int
     p.iterations = iterations;
     p.first_sample = current_sample;
     p.nsamples = 1;
-    int blk = ctx->block;
-    decide_lds_scene(ctx, &p, &blk);
     LaunchConfig lc;
-    launch_cfg(ctx, p, &lc, blk);
+    launch_cfg(ctx, p, &lc);
     EventPair* ep;
     if ((rc = time_begin(ctx, &ep)) != PT_OK) return rc;
     PT_HIP(ctx, launch_trace_ray(p, lc, ctx->stream));
@@ -964,7 +1022,7 @@ static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsa
             EventPair* ep;
             int rc = time_begin(ctx, &ep);
             if (rc != PT_OK) return rc;
-            PT_HIP(ctx, launch_wf_intersect(w, b, ctx->stream));
+            PT_HIP(ctx, launch_wf_intersect(w, b, ctx->cu_count, ctx->stream));
             if ((rc = time_end(ctx, ep)) != PT_OK) return rc;
             PT_HIP(ctx, launch_wf_shade(w, b, ctx->stream));
         }
@@ -989,13 +1047,10 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
     p.first_sample = ctx->current_sample;
     p.nsamples = nsamples;
     if (ctx->variant == 1) {
-        p.lds_scene = 0;
         if ((rc = render_wavefront(ctx, p, nsamples)) != PT_OK) return rc;
         ctx->current_sample += nsamples;
         return PT_OK;
     }
-    int blk = ctx->block;
-    decide_lds_scene(ctx, &p, &blk);
     if (ctx->persistent) {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counter, 0, sizeof(uint32_t), ctx->stream));
         p.tile_counter = ctx->d_tile_counter;
@@ -1007,6 +1062,10 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         const int resident_waves = ctx->cu_count * 16;
         const int auto_chunk = p.n_tiles >= 6 * resident_waves ? 8 : (p.n_tiles > resident_waves + resident_waves / 2 ? 4 : 0);
         const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk;
+        // work items are numbered with an int on the device: passes x tiles + one failed fetch per resident wave
+        const int64_t items = chunk > 0 ? ((int64_t)nsamples + chunk - 1) / chunk * p.n_tiles : p.n_tiles;
+        if (items + (int64_t)resident_waves + 64 >= ((int64_t)1 << 31))
+            return fail(ctx, PT_EINVAL, "nsamples / chunk_spp x tiles does not fit the 31-bit work-item counter of one launch: render in several calls");
         if (chunk > 0 && nsamples > chunk && p.n_tiles > 0) {
             if (!ctx->d_tile_done) PT_HIP(ctx, hipMalloc((void**)&ctx->d_tile_done, sizeof(uint32_t) * (size_t)p.n_tiles));
             PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_done, 0, sizeof(uint32_t) * (size_t)p.n_tiles, ctx->stream));
@@ -1015,7 +1074,7 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         }
     }
     LaunchConfig lc;
-    launch_cfg(ctx, p, &lc, blk);
+    launch_cfg(ctx, p, &lc);
     EventPair* ep;
     if ((rc = time_begin(ctx, &ep)) != PT_OK) return rc;
     PT_HIP(ctx, launch_render_mega(p, lc, ctx->stream));
@@ -1045,6 +1104,74 @@ int pt_sync(pt_context* ctx) {
 int pt_local_pixel_count(const pt_context* ctx, int64_t* out) {
     if (!ctx || !out) return PT_EINVAL;
     *out = ctx->npix;
+    return PT_OK;
+}
+
+int pt_slab_pixel_count(const pt_context* ctx, int64_t* out) {
+    if (!ctx || !out) return PT_EINVAL;
+    *out = ctx->slab_pix;
+    return PT_OK;
+}
+
+int pt_frame_size(const pt_context* ctx, int32_t* width, int32_t* height, int64_t* npix) {
+    if (!ctx) return PT_EINVAL;
+    if (width) *width = ctx->W;
+    if (height) *height = ctx->H;
+    if (npix) *npix = (int64_t)ctx->W * ctx->H;
+    return PT_OK;
+}
+
+// ---- frame assembly over RCCL (pt_comm.hip)
+int pt_comm_unique_id(void* id128) {
+    if (!id128) return PT_EINVAL;
+    std::string err;
+    const int rc = comm_unique_id(id128, &err);
+    return rc == PT_OK ? rc : fail(nullptr, rc, err);
+}
+
+int pt_comm_init(pt_context* ctx, const void* id128) {
+    PT_NEED_DEVICE(ctx);
+    if (!id128) return fail(ctx, PT_EINVAL, "id is NULL");
+    if (ctx->comm) return fail(ctx, PT_EINVAL, "the context already has a communicator");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    const int rc = comm_init(id128, ctx->rank, ctx->world, &ctx->comm, &err);
+    return rc == PT_OK ? rc : fail(ctx, rc, err);
+}
+
+int pt_gather_frame(pt_context* ctx) {
+    PT_NEED_DEVICE(ctx);
+    if (!ctx->comm) {
+        if (ctx->world == 1) return PT_OK;             // the colors buffer IS the frame
+        return fail(ctx, PT_EINVAL, "pt_comm_init has not been called on this tiled context");
+    }
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t slab = (size_t)ctx->slab_pix;
+    if (!ctx->d_gathered) PT_HIP(ctx, hipMalloc((void**)&ctx->d_gathered, sizeof(float4) * slab * (size_t)ctx->world));
+    if (!ctx->d_frame) PT_HIP(ctx, hipMalloc((void**)&ctx->d_frame, sizeof(float4) * (size_t)ctx->W * (size_t)ctx->H));
+    std::string err;
+    const int rc = comm_all_gather(ctx->comm, ctx->d_colors, ctx->d_gathered, slab * 4, ctx->stream, &err);
+    if (rc != PT_OK) return fail(ctx, rc, err);
+    PT_HIP(ctx, launch_deinterleave(ctx->d_gathered, ctx->d_frame, ctx->W, ctx->H, ctx->world, ctx->rows_per_block, (long long)slab, ctx->stream));
+    return PT_OK;
+}
+
+void* pt_device_frame(pt_context* ctx) { return !ctx ? nullptr : (ctx->world == 1 && !ctx->d_frame) ? (void*)ctx->d_colors : (void*)ctx->d_frame; }
+
+int pt_read_frame(pt_context* ctx, float* out, int64_t npix) {
+    PT_NEED_DEVICE(ctx);
+    if (!out || npix != (int64_t)ctx->W * ctx->H) return fail(ctx, PT_EINVAL, "npix must equal width * height of the global frame");
+    const float4* src = (ctx->world == 1 && !ctx->d_frame) ? ctx->d_colors : ctx->d_frame;
+    if (!src) return fail(ctx, PT_EINVAL, "pt_gather_frame has not been called");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(out, src, sizeof(float4) * (size_t)npix, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_debug_gather_index(int32_t width, int32_t height, int32_t world, int32_t rows_per_block, int64_t slab_stride, int64_t* out) {
+    if (width <= 0 || height <= 0 || world < 1 || rows_per_block < 1 || !out) return PT_EINVAL;
+    gather_source_index(width, height, world, rows_per_block, (long long)slab_stride, out);
     return PT_OK;
 }
 
@@ -1132,17 +1259,13 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     if (k == "variant") {
         if (value != 0 && value != 1) return fail(ctx, PT_EINVAL, "variant must be 0 (megakernel) or 1 (wavefront)");
         ctx->variant = (int)value;
-    } else if (k == "block") {
-        if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return fail(ctx, PT_EINVAL, "block must be 64..1024, power of two");
-        ctx->block = (int)value;
     } else if (k == "lds_scene") {
-        if (value < 0 || value > 2) return fail(ctx, PT_EINVAL, "lds_scene: 0 off, 1 nodes + packets in LDS, 2 nodes in LDS");
-        if ((value == 1) != (ctx->lds_scene == 1) && ctx->bvh_policy == 0 && ctx->tris_uploaded) {
-            ctx->lds_scene = (int)value;             // the automatic BVH policy depends on it: rebuild
-            int rc = pt_upload_triangles(ctx);
-            if (rc != PT_OK) return rc;
-        }
+        if (value != 0 && value != 2) return fail(ctx, PT_EINVAL, "lds_scene: 0 every node through L1/L2, 2 stage the tree (or its top) in LDS");
         ctx->lds_scene = (int)value;
+    } else if (k == "treelet") {
+        if (value < -1 || value > 2048) return fail(ctx, PT_EINVAL, "treelet: -1 automatic, 0 off, 2..2048 nodes");
+        ctx->treelet = (int)value;
+        ctx->tris_uploaded = false;                  // the tree is re-indexed at upload
     } else if (k == "timing") {
         ctx->timing = value ? 1 : 0;
     } else if (k == "count_work") {
@@ -1155,19 +1278,11 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "sah_visit_cost") {
         if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "sah_visit_cost: tenths of a triangle test, 0..1000");
         ctx->sah_visit_cost = (int)value;
-    } else if (k == "pixel_map") {
-        ctx->pixel_map = value ? 1 : 0;
-    } else if (k == "debug_lds_pad") {
-        ctx->debug_lds_pad = (int)value;
     } else if (k == "debug_repeat") {
+        if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "debug_repeat: 0..1000 extra timed launches");
         ctx->debug_repeat = (int)value;
     } else if (k == "cost_binning") {
         ctx->cost_binning = value ? 1 : 0;
-    } else if (k == "traversal") {
-        if (value < 0 || value > 64) return fail(ctx, PT_EINVAL, "traversal: 0 while-while, 1 voting, n >= 2 sliced with n-1 rounds per trip");
-        ctx->traversal = (int)value;
-    } else if (k == "min_waves") {
-        ctx->min_waves = (int)value;
     } else if (k == "bvh_policy") {
         if (value < 0 || value > 4) return fail(ctx, PT_EINVAL, "bvh_policy must be 0..4 (4 = device LBVH)");
         ctx->bvh_policy = (int)value;
@@ -1197,6 +1312,15 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out) {
     if (k == "bvh_on_device") { *out = (double)ctx->bvh_on_device; return PT_OK; }
     if (k == "triangles") { *out = (double)ctx->orig.size(); return PT_OK; }
     if (k == "lds_bytes") { *out = (double)ctx->last_lds_bytes; return PT_OK; }
+    if (k == "treelet_nodes") { *out = (double)ctx->treelet_nodes; return PT_OK; }
+    if (k == "node_mode") {      // what the next launch will use: 0 whole tree in LDS, 1 L1/L2 only, 2 treelet
+        pt_camera cam;
+        std::memset(&cam, 0, sizeof cam);
+        RenderParams p;
+        fill_params(ctx, &cam, &p);
+        *out = (double)p.node_mode;
+        return PT_OK;
+    }
     if (k == "kernel_launches") { *out = (double)ctx->kernel_launches; return PT_OK; }
     PT_NEED_DEVICE(ctx);
     PT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1235,6 +1359,18 @@ int pt_debug_bvh_copy(const pt_context* ctx, float* nodes, float* tris, int32_t*
     return PT_OK;
 }
 
+namespace {
+struct DeviceBuf {          // frees on every exit path
+    void* p = nullptr;
+    ~DeviceBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 16)); }
+};
+struct EventOwner {
+    hipEvent_t e = nullptr;
+    ~EventOwner() { if (e) (void)hipEventDestroy(e); }
+};
+}  // namespace
+
 int pt_debug_closest_hit(pt_context* ctx, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri) {
     PT_NEED_DEVICE(ctx);
     if (!rays || !out_t || !out_tri || n < 0) return fail(ctx, PT_EINVAL, "bad arguments");
@@ -1243,43 +1379,50 @@ int pt_debug_closest_hit(pt_context* ctx, const pt_ray* rays, int64_t n, float* 
     pt_camera cam;
     std::memset(&cam, 0, sizeof cam);
     RenderParams p;
-    fill_params(ctx, &cam, &p);
-    pt_ray* d_rays = nullptr;
-    float* d_t = nullptr;
-    int32_t* d_tri = nullptr;
-    const size_t nn = (size_t)std::max<int64_t>(n, 1);
-    PT_HIP(ctx, hipMalloc((void**)&d_rays, sizeof(pt_ray) * nn));
-    PT_HIP(ctx, hipMalloc((void**)&d_t, sizeof(float) * nn));
-    PT_HIP(ctx, hipMalloc((void**)&d_tri, sizeof(int32_t) * nn));
-    PT_HIP(ctx, hipMemcpy(d_rays, rays, sizeof(pt_ray) * (size_t)n, hipMemcpyHostToDevice));
-    // same node path as the render kernel would take: nodes staged in LDS (swizzled quads, 16-bit
-    // references, one-fma slab test) when the scene qualifies, otherwise straight from global memory
-    int blk = 0;
-    decide_lds_scene(ctx, &p, &blk);
-    PT_HIP(ctx, launch_debug_closest_hit(p, d_rays, n, d_t, d_tri, ctx->stream, p.lds_scene == 2 ? 2 : 0));
+    fill_params(ctx, &cam, &p);         // same node placement as the render kernels would use
+    DeviceBuf d_rays, d_t, d_tri;
+    PT_HIP(ctx, d_rays.alloc(sizeof(pt_ray) * (size_t)n));
+    PT_HIP(ctx, d_t.alloc(sizeof(float) * (size_t)n));
+    PT_HIP(ctx, d_tri.alloc(sizeof(int32_t) * (size_t)n));
+    if (n) PT_HIP(ctx, hipMemcpy(d_rays.p, rays, sizeof(pt_ray) * (size_t)n, hipMemcpyHostToDevice));
+    ctx->last_lds_bytes = traversal_lds_bytes(p, traversal_block(p.node_mode));
+    PT_HIP(ctx, launch_debug_closest_hit(p, (const pt_ray*)d_rays.p, n, (float*)d_t.p, (int32_t*)d_tri.p, ctx->cu_count, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->debug_repeat > 0) {      // traversal-only timing: the same launch, debug_repeat times
-        hipEvent_t e0, e1;
-        PT_HIP(ctx, hipEventCreate(&e0));
-        PT_HIP(ctx, hipEventCreate(&e1));
-        PT_HIP(ctx, hipEventRecord(e0, ctx->stream));
-        for (int r = 0; r < ctx->debug_repeat; ++r) PT_HIP(ctx, launch_debug_closest_hit(p, d_rays, n, d_t, d_tri, ctx->stream, (size_t)ctx->debug_lds_pad));
-        PT_HIP(ctx, hipEventRecord(e1, ctx->stream));
-        PT_HIP(ctx, hipEventSynchronize(e1));
+        EventOwner e0, e1;
+        PT_HIP(ctx, hipEventCreate(&e0.e));
+        PT_HIP(ctx, hipEventCreate(&e1.e));
+        PT_HIP(ctx, hipEventRecord(e0.e, ctx->stream));
+        for (int r = 0; r < ctx->debug_repeat; ++r)
+            PT_HIP(ctx, launch_debug_closest_hit(p, (const pt_ray*)d_rays.p, n, (float*)d_t.p, (int32_t*)d_tri.p, ctx->cu_count, ctx->stream));
+        PT_HIP(ctx, hipEventRecord(e1.e, ctx->stream));
+        PT_HIP(ctx, hipEventSynchronize(e1.e));
         float ms = 0.f;
-        PT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        PT_HIP(ctx, hipEventElapsedTime(&ms, e0.e, e1.e));
         ctx->kernel_ms_acc += ms;
         ctx->kernel_launches += ctx->debug_repeat;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
     }
-    PT_HIP(ctx, hipMemcpy(out_t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
-    PT_HIP(ctx, hipMemcpy(out_tri, d_tri, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    if (n) {
+        PT_HIP(ctx, hipMemcpy(out_t, d_t.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+        PT_HIP(ctx, hipMemcpy(out_tri, d_tri.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    }
     for (int64_t i = 0; i < n; ++i)
         if (out_tri[i] >= 0) out_tri[i] = ctx->orig[(size_t)out_tri[i]];      // packed -> add order
-    (void)hipFree(d_rays);
-    (void)hipFree(d_t);
-    (void)hipFree(d_tri);
+    return PT_OK;
+}
+
+int pt_debug_deinterleave(pt_context* ctx, const float* gathered, int64_t n_pixels, float* out_frame) {
+    PT_NEED_DEVICE(ctx);
+    if (!gathered || !out_frame || n_pixels != ctx->slab_pix * ctx->world) return fail(ctx, PT_EINVAL, "gathered must hold world x slab pixels");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceBuf d_g, d_f;
+    const size_t nf = (size_t)ctx->W * (size_t)ctx->H;
+    PT_HIP(ctx, d_g.alloc(sizeof(float4) * (size_t)n_pixels));
+    PT_HIP(ctx, d_f.alloc(sizeof(float4) * nf));
+    PT_HIP(ctx, hipMemcpy(d_g.p, gathered, sizeof(float4) * (size_t)n_pixels, hipMemcpyHostToDevice));
+    PT_HIP(ctx, launch_deinterleave((const float4*)d_g.p, (float4*)d_f.p, ctx->W, ctx->H, ctx->world, ctx->rows_per_block, (long long)ctx->slab_pix, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(out_frame, d_f.p, sizeof(float4) * nf, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

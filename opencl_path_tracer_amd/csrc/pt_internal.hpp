@@ -38,6 +38,13 @@ struct TriMeta {
     int32_t mati;
 };
 
+// Where the traversal reads BVH nodes from (Trav<MODE> in pt_device.hpp)
+enum : int { kNodesLds = 0, kNodesGlobal = 1, kNodesTreelet = 2 };
+
+// Packets and nodes are addressed with 32-bit byte offsets on the device (index * 48, index << 6) and a
+// leaf reference holds first << 3 in 31 bits: 2^26 triangles (hence < 2^26 nodes) keep all three in range.
+constexpr int64_t kMaxTriangles = (int64_t)1 << 26;
+
 constexpr int kMaxLeaf = 4;        // triangles per leaf (<= 8 by the reference encoding)
 constexpr int kMaxDepth = 30;      // builder guarantees depth <= kMaxDepth
 constexpr int kStatRows = 256;     // statistics counters are spread over this many rows of 8
@@ -59,14 +66,14 @@ struct RenderParams {
     int32_t rank, world, rows_per_block;
     int32_t iterations, first_sample, nsamples;
     int32_t n_nodes, n_tris;
-    int32_t lds_scene;           // 1: stage nodes+triangles in LDS
-    int32_t stack_entries;       // per-lane stack depth actually needed (BVH depth + 1)
+    int32_t node_mode;           // kNodesLds / kNodesGlobal / kNodesTreelet: where the traversal reads BVH nodes from
+    int32_t treelet_nodes;       // kNodesTreelet: nodes [0, treelet_nodes) are staged in LDS
+    int32_t stack_entries;       // per-lane stack depth actually needed (sentinel + BVH depth + the slot above the top)
     uint32_t* tile_counter;      // != 0: persistent launch, waves pull tile indices from this counter
     int32_t n_tiles;
     int32_t chunk_spp;           // > 0: a work item is (pass, tile) = chunk_spp samples of a tile; passes of one
                                  // tile are chained through tile_done[] (agent-scope release / acquire)
     uint32_t* tile_done;         // [n_tiles] number of passes completed, zeroed before the launch
-    int32_t pixel_map;           // 0: one wave = one 8x8 tile; 1: lane l of wave w owns pixel l*n_waves + w
 };
 
 // ---- wavefront (stream-compacted) formulation
@@ -110,25 +117,23 @@ struct LbvhResult {
 hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, hipStream_t stream, LbvhResult* out);
 
 struct LaunchConfig {
-    int block = 256;
-    size_t lds_bytes = 0;
-    int min_waves = 1;         // __launch_bounds__ second argument (waves per SIMD the allocator must allow)
-    int traversal = 0;         // 0 while-while rounds, 1 wave-voting single steps
+    int block = 256;                   // traversal_block(node_mode)
+    size_t lds_bytes = 0;              // traversal_lds_bytes()
     int persistent_blocks = 1 << 30;   // grid size of a persistent launch (workgroups that fit the chip)
-    bool count_work = false;   // also count node visits / triangle tests into stats[2], stats[3]
+    bool count_work = false;           // also count node visits / triangle tests into stats[2..6]
 };
 
-// launchers implemented in pt_kernels.hip; all asynchronous on `stream`
-hipError_t launch_gen_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream);
+// launchers (pt_kernels.hip, pt_wavefront.hip, pt_debug.hip); all asynchronous on `stream`
+int traversal_block(int node_mode);                            // threads per workgroup of the traversal kernels
+size_t traversal_lds_bytes(const RenderParams& p, int block);  // stacks + staged nodes
+hipError_t launch_gen_ray(const RenderParams& p, hipStream_t stream);
 hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream);
 hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream);
 hipError_t launch_resolve_reinhard(const float4* colors, float4* out, int64_t n, hipStream_t stream);
 hipError_t launch_filt_im(const float4* colors, float4* out, int32_t width, int32_t height, hipStream_t stream);
 hipError_t launch_wf_generate(const WfParams& p, hipStream_t stream);
-hipError_t launch_wf_intersect(const WfParams& p, int bounce, hipStream_t stream);
+hipError_t launch_wf_intersect(const WfParams& p, int bounce, int cu_count, hipStream_t stream);
 hipError_t launch_wf_shade(const WfParams& p, int bounce, hipStream_t stream);
-hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, hipStream_t stream, size_t lds_pad = 0);
-size_t mega_lds_bytes(const RenderParams& p, int block);
-int mega_max_lds_scene_bytes();
+hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, int cu_count, hipStream_t stream);
 
 }  // namespace ptamd

@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) k_pack(const unsigned long long* keys, in
 #define LB_HIP(call)                                                          \
     do {                                                                      \
         hipError_t e_ = (call);                                               \
-        if (e_ != hipSuccess) { cleanup(); return e_; }                       \
+        if (e_ != hipSuccess) { cleanup_all(); return e_; }                       \
     } while (0)
 
 }  // namespace
@@ -285,7 +285,6 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, h
         if (d_meta) (void)hipFree(d_meta);
         if (d_orig) (void)hipFree(d_orig);
     };
-    (void)cleanup_all;
     const int ni = n - 1;
     const int blocks_n = (n + 255) / 256, blocks_i = (ni + 255) / 256;
     LB_HIP(hipMalloc((void**)&d_tris, sizeof(pt_triangle) * (size_t)n));
@@ -337,7 +336,7 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, h
     LB_HIP(hipMemcpyAsync(&depth, d_misc + 6, sizeof(int), hipMemcpyDeviceToHost, stream));
     LB_HIP(hipStreamSynchronize(stream));
     const int n_out = last_idx + last_flag;
-    if (n_out < 1) { cleanup(); return hipErrorUnknown; }
+    if (n_out < 1) { cleanup_all(); return hipErrorUnknown; }
     LB_HIP(hipMalloc((void**)&d_out, sizeof(Node64) * (size_t)n_out));
     LB_HIP(hipMalloc((void**)&d_packets, sizeof(TriPacket) * (size_t)n));
     LB_HIP(hipMalloc((void**)&d_meta, sizeof(TriMeta) * (size_t)n));

@@ -1,0 +1,322 @@
+// pt_wavefront.hip -- the stream-compacted ("wavefront") formulation of the same path
+// (BASELINE north_star; option variant = 1).  Device helpers: pt_device.hpp.
+#include "pt_device.hpp"
+
+#include <algorithm>
+
+namespace ptamd {
+
+// ============================================================================ wavefront
+// Stream-compacted formulation of the same path (BASELINE north_star): one pass = one sample of
+// every local pixel.  generate -> for each bounce { intersect ; shade } with the path state SoA in
+// HBM (WfParams) and index queues between the stages.
+//   wf_generate : 2 LCG draws + camera ray per pixel (prog.cl:384-389), state init (prog.cl:307-316)
+//   wf_intersect: each wave owns 256 consecutive entries of a ray queue and refills a lane as soon
+//                 as its traversal ends (__ballot/__popcll rank inside the wave's range), so no
+//                 lane idles while its neighbours finish long traversals.  At the end the block
+//                 compacts its rays into three class queues by the material type they hit
+//                 (order-preserving ballot scan through LDS, 3 global atomics per 1,024 rays).
+//   wf_shade    : one block row per class -> waves are material-coherent.  Survivors go to the
+//                 next bounce's ray queues; paths that end (miss / last bounce) fold their colour
+//                 into the running mean (prog.cl:379) and store the LCG state.
+// Ray queues come in two COST classes: a ray that misses the bounding boxes of every complex
+// object (more than 16 triangles) can only hit the few large triangles around them and finishes
+// in a handful of steps; mixing it into a wave with rays that walk a 1,000-triangle object leaves
+// its lane idle for most of the wave's life (measured: 16 % lane utilisation in the node loop).
+PT_DEV unsigned long long lanemask_lt() {
+    const unsigned lane = threadIdx.x & 63;
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// Order-preserving slot reservation: every thread with cls in [0, NCLS) gets the next free
+// position of stream/queue `cls` (count at counters[cls]); returns it, or ~0u.  Every thread of the
+// block must call it.  scratch: NCLS*(WAVES+1) words.
+template <int NCLS, int BLOCK>
+PT_DEV unsigned block_reserve(int cls, unsigned* counters, unsigned* scratch) {
+    constexpr int WAVES = BLOCK / 64;
+    const unsigned wave = threadIdx.x >> 6;
+    const unsigned long long lt = lanemask_lt();
+    unsigned myoff = 0;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if ((threadIdx.x & 63) == 0) scratch[c * (WAVES + 1) + wave] = (unsigned)__popcll(m);
+        if (cls == c) myoff = (unsigned)__popcll(m & lt);
+    }
+    __syncthreads();
+    if (threadIdx.x < NCLS) {
+        unsigned* row = scratch + threadIdx.x * (WAVES + 1);
+        unsigned tot = 0;
+        for (int k = 0; k < WAVES; ++k) { const unsigned v = row[k]; row[k] = tot; tot += v; }
+        row[WAVES] = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0u;
+    }
+    __syncthreads();
+    unsigned pos = ~0u;
+    if (cls >= 0 && cls < NCLS) {
+        const unsigned* row = scratch + cls * (WAVES + 1);
+        pos = row[WAVES] + row[wave] + myoff;
+    }
+    __syncthreads();
+    return pos;
+}
+
+// 1 = the ray touches the box of a complex object (expensive traversal ahead), 0 = it cannot
+PT_DEV int ray_cost_class(const WfParams& w, f3 P, f3 D) {
+    const f3 inv = mk(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
+    int cost = 0;
+    for (int b = 0; b < w.n_cbox; ++b) {
+        const float x0 = (w.cbox[b][0] - P.x) * inv.x, x1 = (w.cbox[b][3] - P.x) * inv.x;
+        const float y0 = (w.cbox[b][1] - P.y) * inv.y, y1 = (w.cbox[b][4] - P.y) * inv.y;
+        const float z0 = (w.cbox[b][2] - P.z) * inv.z, z1 = (w.cbox[b][5] - P.z) * inv.z;
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * 1.0000005f;
+        if (tf >= tn && tf >= 0.0f) cost = 1;
+    }
+    return cost;
+}
+
+PT_DEV void wf_finalize(const WfParams& w, int li, f3 color, int seed) {
+    f3 acc = mk(0.0f, 0.0f, 0.0f);
+    if (w.sample != 0) {
+        const float4 c = w.rp.colors[li];
+        acc = mk(c.x, c.y, c.z);
+    }
+    acc = running_mean(acc, color, w.sample);
+    w.rp.colors[li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    w.rp.rnds[li] = seed;
+}
+
+__global__ void __launch_bounds__(256) wf_generate(WfParams w) {
+    __shared__ unsigned s_scratch[2 * 5];
+    const int li = blockIdx.x * 256 + threadIdx.x;
+    const RenderParams& p = w.rp;
+    // rows >= 1 (bounces >= 1) are cleared here; row 0 (bounce 0, filled by THIS launch) is cleared by
+    // a memset the host enqueues in front of the kernel
+    if (li >= kWfCounterStride && li < (p.iterations + 3) * kWfCounterStride) w.counters[li] = 0u;
+    int cost = -1;
+    f3 P = mk(0.f, 0.f, 0.f), D = mk(0.f, 0.f, 1.f);
+    if (li < w.npix) {
+        const int lrow = li / p.width, x = li - lrow * p.width;
+        const int grow = ((lrow / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (lrow % p.rows_per_block);
+        const int gid = grow * p.width + x;
+        int seed = p.rnds[li];
+        const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+        camera_get_ray(gid, p.cam, rnd1, rnd2, &P, &D);
+        if (p.iterations <= 0) {
+            wf_finalize(w, li, mk(0.0f, 0.0f, 0.0f), seed);
+        } else {
+            w.sC[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            w.sD[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            w.sE[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            w.sF[li] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(seed));
+            cost = ray_cost_class(w, P, D);
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && li < w.npix && p.stats) stat_add(p, 1, (unsigned long long)min(64, w.npix - li));
+    const unsigned pos = block_reserve<2, 256>(cost, w.counters + kWfGenRow * kWfCounterStride, s_scratch);
+    if (cost >= 0) {
+        w.rsA[0][cost][pos] = make_float4(P.x, P.y, P.z, D.x);
+        w.rsB[0][cost][pos] = make_float4(D.y, D.z, __int_as_float(li), 0.0f);
+    }
+}
+
+// Rays per wave: each wave owns a contiguous range of the bounce's ray stream (no global atomics
+// on the fetch side; blocks that finish early are replaced by the dispatcher).
+constexpr int kWfRaysPerWave = 256;
+
+// Flat traversal loop: every iteration each lane performs at most one node visit and then at most
+// one triangle test, and a lane whose ray is finished takes the next ray of the wave's range in the
+// SAME iteration (the next ray's 32 B are prefetched one assignment ahead, so the switch costs no
+// memory round trip).  No lane ever waits for another lane's traversal to end.
+template <int MODE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
+    typedef typename StackOf<MODE>::type StackT;
+    constexpr int WAVES = BLOCK / 64;
+    constexpr int RPB = WAVES * kWfRaysPerWave;          // rays per block and trip
+    constexpr int CHUNKS = RPB / 64;
+    const RenderParams& p = w.rp;
+    const int cost = blockIdx.y;
+    unsigned* ctr = w.counters + wf_row(bounce) * kWfCounterStride;
+    const unsigned n = ctr[cost];
+    if (blockIdx.x * RPB >= n) return;                    // uniform for the whole block
+    // dynamic LDS: [traversal stacks][staged nodes][class byte per ray of the trip][CHUNKS x 3 counts][3 bases]
+    LaneStack<StackT> stk;
+    SceneView sv;
+    setup_traversal<MODE, BLOCK>(p, &sv, &stk);
+    unsigned char* lds_cls = pt_lds_raw + traversal_lds_bytes_dev<MODE, BLOCK>(p);
+    unsigned* lds_cnt = reinterpret_cast<unsigned*>(lds_cls + RPB);     // [CHUNKS][3]
+    unsigned* lds_base = lds_cnt + CHUNKS * 3;                          // [3]
+    const float4* __restrict__ rsA = w.rsA[bounce & 1][cost];
+    const float4* __restrict__ rsB = w.rsB[bounce & 1][cost];
+    float2* __restrict__ hits = w.hit[cost];
+    const unsigned long long lt = lanemask_lt();
+    const unsigned wave = threadIdx.x >> 6;
+    WorkCount wc;
+    // the grid only fills the chip: a block takes the trips block_base = blockIdx.x * RPB, + gridDim.x * RPB, ...
+    // (the nodes are staged once per block, not once per 1,024 rays)
+    for (unsigned block_base = blockIdx.x * RPB; block_base < n; block_base += gridDim.x * RPB) {
+        unsigned cbase = block_base + wave * kWfRaysPerWave;  // uniform per wave: next unassigned ray
+        const unsigned cend = min(cbase + (unsigned)kWfRaysPerWave, n);
+        if (cbase > cend) cbase = cend;
+        Trav<MODE> tr;
+        tr.begin(mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), stk);
+        tr.idle();
+        unsigned pos = ~0u;          // stream position of the ray in flight (~0u: none)
+        unsigned npos = ~0u;         // prefetched next ray (~0u: none)
+        float4 nA = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 nB = make_float2(0.f, 1.f);
+        for (;;) {
+            // ---- lanes whose ray is finished switch to their prefetched ray
+            if (tr.done() && npos != ~0u) {
+                pos = npos;
+                npos = ~0u;
+                tr.begin(mk(nA.x, nA.y, nA.z), mk(nA.w, nB.x, nB.y), stk);
+            }
+            // ---- lanes without a prefetched ray reserve the next positions of the wave's range
+            const unsigned long long want = __ballot(npos == ~0u);
+            if (want != 0 && cbase < cend) {
+                const unsigned my = cbase + (unsigned)__popcll(want & lt);
+                if (npos == ~0u && my < cend) {
+                    npos = my;
+                    nA = rsA[my];
+                    nB = *reinterpret_cast<const float2*>(&rsB[my]);
+                }
+                cbase = min(cbase + (unsigned)__popcll(want), cend);
+            }
+            if (__ballot(!tr.done() || npos != ~0u) == 0) break;
+            // ---- one node visit, then one triangle test
+            if (tr.is_node(tr.cur)) tr.template node_step_any<false>(sv, &wc);
+            if (tr.is_leaf(tr.cur)) tr.template leaf_step<false>(sv, &wc);
+            // ---- finished: hit record + class byte
+            if (tr.done() && pos != ~0u) {
+                hits[pos] = make_float2(tr.best_t, __int_as_float(tr.best));
+                int cls = 2;
+                if (tr.best >= 0) {
+                    const int type = p.mats[sv.meta[tr.best].mati].type;
+                    cls = (type == 0 || type == 3) ? 0 : 1;
+                }
+                lds_cls[pos - block_base] = (unsigned char)cls;
+                pos = ~0u;
+            }
+        }
+        // ---- order-preserving compaction of the trip's rays into the three class queues
+        __syncthreads();
+        const unsigned nblock = min((unsigned)RPB, n - block_base);
+        unsigned off[RPB / BLOCK];
+        int cl[RPB / BLOCK];
+#pragma unroll
+        for (int k = 0; k < RPB / BLOCK; ++k) {
+            const unsigned r = k * BLOCK + threadIdx.x;
+            cl[k] = r < nblock ? (int)lds_cls[r] : -1;
+            off[k] = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned long long m = __ballot(cl[k] == c);
+                if ((threadIdx.x & 63) == 0) lds_cnt[(r >> 6) * 3 + c] = (unsigned)__popcll(m);
+                if (cl[k] == c) off[k] = (unsigned)__popcll(m & lt);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            unsigned tot = 0;
+            for (int ch = 0; ch < CHUNKS; ++ch) { const unsigned v = lds_cnt[ch * 3 + threadIdx.x]; lds_cnt[ch * 3 + threadIdx.x] = tot; tot += v; }
+            lds_base[threadIdx.x] = tot ? atomicAdd(&ctr[2 + threadIdx.x], tot) : 0u;
+        }
+        if (threadIdx.x == 0 && p.stats) stat_add(p, 0, (unsigned long long)nblock);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPB / BLOCK; ++k) {
+            const unsigned r = k * BLOCK + threadIdx.x;
+            if (cl[k] >= 0) w.q_cls[cl[k]][lds_base[cl[k]] + lds_cnt[(r >> 6) * 3 + cl[k]] + off[k]] = (int)(((unsigned)cost << 31) | (block_base + r));
+        }
+        __syncthreads();            // lds_cls / lds_cnt are rewritten by the next trip
+    }
+}
+
+constexpr int kWfShadeBlock = 1024;
+
+__global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce) {
+    __shared__ unsigned s_scratch[2 * (kWfShadeBlock / 64 + 1)];
+    const RenderParams& p = w.rp;
+    const int cls = blockIdx.y;
+    unsigned* ctr = w.counters + wf_row(bounce) * kWfCounterStride;
+    const unsigned n = ctr[2 + cls];
+    if (blockIdx.x * kWfShadeBlock >= n) return;          // whole block idle
+    const unsigned i = blockIdx.x * kWfShadeBlock + threadIdx.x;
+    int li = 0;
+    int cost = -1;                                        // >= 0: the path continues with a ray of that cost class
+    f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
+    if (i < n) {
+        const unsigned e = (unsigned)w.q_cls[cls][i];
+        const int c_in = (int)(e >> 31);
+        const unsigned pos = e & 0x7fffffffu;
+        const float4 A = w.rsA[bounce & 1][c_in][pos], B = w.rsB[bounce & 1][c_in][pos];
+        li = __float_as_int(B.z);
+        const float4 F = w.sF[li];
+        f3 color = mk(F.x, F.y, F.z);
+        const int sbits = __float_as_int(F.w);
+        int seed = sbits & 0x7fffffff;
+        bool inside = sbits < 0;
+        if (cls == 2) {                                   // miss: black environment, prog.cl:367-376
+            wf_finalize(w, li, color, seed);
+        } else {
+            const float2 h = w.hit[c_in][pos];
+            const float4 C = w.sC[li], Dq = w.sD[li], E = w.sE[li];
+            rP = mk(A.x, A.y, A.z);
+            rD = mk(A.w, B.x, B.y);
+            f3 fL = mk(C.x, C.y, C.z), fB = mk(C.w, Dq.x, Dq.y), fS = mk(Dq.z, Dq.w, E.x), fR = mk(E.y, E.z, E.w);
+            shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, p.tris, p.meta, __float_as_int(h.y), h.x);
+            if (bounce + 1 >= p.iterations) {
+                wf_finalize(w, li, color, seed);
+            } else {
+                w.sC[li] = make_float4(fL.x, fL.y, fL.z, fB.x);
+                w.sD[li] = make_float4(fB.y, fB.z, fS.x, fS.y);
+                w.sE[li] = make_float4(fS.z, fR.x, fR.y, fR.z);
+                w.sF[li] = make_float4(color.x, color.y, color.z, __int_as_float(seed | (inside ? (int)0x80000000 : 0)));
+                cost = ray_cost_class(w, rP, rD);
+            }
+        }
+    }
+    const unsigned npos = block_reserve<2, kWfShadeBlock>(cost, w.counters + wf_row(bounce + 1) * kWfCounterStride, s_scratch);
+    if (cost >= 0) {
+        w.rsA[(bounce + 1) & 1][cost][npos] = make_float4(rP.x, rP.y, rP.z, rD.x);
+        w.rsB[(bounce + 1) & 1][cost][npos] = make_float4(rD.y, rD.z, __int_as_float(li), 0.0f);
+    }
+}
+
+hipError_t launch_wf_generate(const WfParams& w, hipStream_t stream) {
+    const int need = std::max(w.npix, (w.rp.iterations + 3) * kWfCounterStride);
+    hipLaunchKernelGGL(wf_generate, dim3((need + 255) / 256), dim3(256), 0, stream, w);
+    return hipGetLastError();
+}
+
+template <int MODE, int BLOCK>
+static hipError_t launch_wf_intersect_t(const WfParams& w, int bounce, int resident_blocks, hipStream_t stream) {
+    constexpr int RPB = (BLOCK / 64) * kWfRaysPerWave;
+    const size_t lds = traversal_lds_bytes(w.rp, BLOCK) + RPB + (RPB / 64) * 3 * 4 + 32;
+    auto kern = wf_intersect<MODE, BLOCK>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int blocks = std::min((w.npix + RPB - 1) / RPB, resident_blocks);
+    hipLaunchKernelGGL(kern, dim3(blocks, 2), dim3(BLOCK), lds, stream, w, bounce);
+    return hipGetLastError();
+}
+
+hipError_t launch_wf_intersect(const WfParams& w, int bounce, int cu_count, hipStream_t stream) {
+    // grid: what is resident at once (per cost class row; the rows of a launch share the chip)
+    switch (w.rp.node_mode) {
+    case kNodesLds: return launch_wf_intersect_t<kNodesLds, 512>(w, bounce, cu_count * 2, stream);
+    case kNodesGlobal: return launch_wf_intersect_t<kNodesGlobal, 256>(w, bounce, cu_count * 8, stream);
+    case kNodesTreelet: return launch_wf_intersect_t<kNodesTreelet, 1024>(w, bounce, cu_count, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_wf_shade(const WfParams& w, int bounce, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_shade, dim3((w.npix + kWfShadeBlock - 1) / kWfShadeBlock, 3), dim3(kWfShadeBlock), 0, stream, w, bounce);
+    return hipGetLastError();
+}
+
+}  // namespace ptamd

@@ -53,11 +53,12 @@ def exchange_frame(slab, tmap, index=None, gathered=None, frame=None, group=None
         frame = torch.empty((tmap.width * tmap.height + 1, C), dtype=slab.dtype, device=slab.device)
     if index is None:
         index = tmap.gather_index(slab.device)
-    try:
-        dist.all_gather_into_tensor(gathered, slab, group=group)
-    except (RuntimeError, NotImplementedError):
+    # one collective, chosen by the backend and never switched at run time: a RuntimeError of the collective
+    # is a real error and propagates (a rank-local fallback would post a mismatched collective)
+    if dist.get_backend(group) == "gloo":
         parts = list(gathered.view(world, tmap.max_count, C).unbind(0))
-        dist.all_gather(parts, slab, group=group)
-        gathered = torch.cat([p.reshape(tmap.max_count, C) for p in parts], 0)
+        dist.all_gather(parts, slab, group=group)          # writes into the views of `gathered`
+    else:
+        dist.all_gather_into_tensor(gathered, slab, group=group)
     frame.index_copy_(0, index, gathered)
     return frame[: tmap.width * tmap.height]

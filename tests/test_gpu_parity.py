@@ -82,34 +82,19 @@ def test_split_api_equals_fused(api, oracle, cb_spec, cb_oracle_scene):
     assert same_bits(r2["D"][:, :3], fr2.rays()["D"][:, :3]) and np.array_equal(c.read_rnds(), fr2.rnds())
 
 
-@pytest.mark.parametrize("lds,block", [(1, 256), (0, 256), (0, 64), (0, 512), (0, 1024), (1, 128), (2, 256)])
-def test_variants_identical(api, oracle, cb_spec, cb_oracle_scene, lds, block):
+@pytest.mark.parametrize("lds", [2, 0])
+def test_node_paths_identical(api, oracle, cb_spec, cb_oracle_scene, lds):
+    """Whole tree staged in LDS (default) and every node through L1/L2: same frame."""
     W, H = 96, 72
     sc = api.Scene(W, H).load(cb_spec)
     sc.set_option("lds_scene", lds)
-    sc.set_option("block", block)
+    assert sc.stat("node_mode") == (0 if lds else 1)
     sc.iterations = 8
     sc.render(2)
     sc.render(2)                                   # continues from current_sample = 2
     fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 8, 4)
-    check(sc, fr, "lds=%d block=%d" % (lds, block))
-
-
-def test_whole_scene_in_lds(api, oracle, cb_spec, cb_oracle_scene):
-    """Option lds_scene = 1 requested BEFORE the triangles are uploaded: the builder picks a
-    fatter-leaved tree so that nodes + packets + stacks fit the LDS of one CU, and the kernel
-    stages both (stage_scene).  Same frame as the oracle; the LDS footprint shows the mode was
-    really taken (it is not the default: 0.75x of the nodes-only mode)."""
-    W, H = 96, 72
-    sc = api.Scene(W, H)
-    sc.set_option("lds_scene", 1)
-    sc.load(cb_spec)
-    sc.iterations = 8
-    sc.render(3)
-    assert sc.stat("lds_bytes") > 100 * 1024
-    fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 8, 3)
-    check(sc, fr, "whole scene in LDS")
-    assert sc.stat("segments") == segs
+    check(sc, fr, "lds_scene=%d" % lds)
+    assert (sc.stat("lds_bytes") > 60 * 1024) == (lds == 2)
 
 
 @pytest.mark.parametrize("lds_scene", [2, 0])
@@ -192,19 +177,29 @@ def test_tiled_ranks_union_equals_single(api, oracle, cb_spec, cb_oracle_scene):
         assert seen.all()
 
 
-def test_mesh_scene_global_memory_path(api, oracle):
-    """A scene too large for LDS staging (displaced grid, ~6k triangles, all four material types
-    reachable) goes through the global-memory traversal; parity bar unchanged."""
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("lds,treelet", [(2, -1), (2, 40), (0, -1)])
+def test_mesh_scene_treelet_and_global_paths(api, oracle, lds, treelet, variant):
+    """A scene too large for whole-tree staging (displaced grid, ~6k triangles, ~3k nodes, all four
+    material types reachable): the top of the tree is staged in LDS (treelet: automatic size, or only 40
+    nodes so that most visits cross between the two node paths) or every node is read through L1/L2;
+    megakernel and wavefront; parity bar unchanged."""
     from opencl_path_tracer_amd import scenes
     spec = scenes.displaced_grid_mesh(6000)
     osc = oracle.load_scene(spec)
     W = H = 64
-    sc = api.Scene(W, H).load(spec)
+    sc = api.Scene(W, H)
+    sc.set_option("treelet", treelet)
+    sc.set_option("lds_scene", lds)
+    sc.set_option("variant", variant)
+    sc.load(spec)
+    assert sc.stat("node_mode") == (2 if lds else 1)
+    if lds and treelet == 40:
+        assert sc.stat("treelet_nodes") == 40
     sc.iterations = 6
     sc.render(3)
-    assert sc.stat("lds_bytes") < 100 * 1024
     fr, _ = oracle_render(oracle, osc, spec, W, H, 6, 3)
-    check(sc, fr, "mesh")
+    check(sc, fr, "mesh lds=%d treelet=%d variant=%d" % (lds, treelet, variant))
 
 
 def test_oracle_modes_agree_with_gpu_on_exhaustive_search(api, oracle, cb_spec, cb_oracle_scene):
@@ -382,9 +377,11 @@ def test_cpp_dropin_host_program(oracle):
     sc.add_Triangle((-10000.0, 0.0, -10000.0), (-10000.0, 0.0, 10000.0), (10000.0, 0.0, 10000.0), 1)
     sc.add_Triangle((10000.0, 0.0, 10000.0), (10000.0, 0.0, -10000.0), (-10000.0, 0.0, -10000.0), 1)
     sc.end_Obj()
-    cam = oracle.make_camera(60, 0, 0, (0, 0, 0), W, H)
+    # the program leaves the view globals at their defaults = the reference's shipped values (main.cpp:30-39)
+    cam = oracle.make_camera(75.0, -13.800002 - 50, 5.599997 + 10, (265.055481, 162.305969, 360.414001), W, H)
     fr = oracle.OracleFrame(W, H)
     fr.render(sc, cam, 4, 0, S, nthreads=8)
+    assert float(fr.colors()[:, :3].sum()) > 0
     h = 1469598103934665603
     for u in fr.colors()[:, :3].copy().view(np.uint32).reshape(-1).tolist():
         h = ((h ^ u) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
@@ -426,8 +423,9 @@ def test_wavefront_tiled_and_mesh(api, oracle, cb_spec, cb_oracle_scene):
     check(sc, fr2, "wavefront mesh")
 
 
-@pytest.mark.parametrize("ntris,W,H,bounces,spp,variant", [(100000, 96, 64, 8, 2, 0), (100000, 64, 48, 8, 2, 1), (1000000, 48, 48, 16, 2, 0)])
-def test_mesh_configs_c3_c5(api, oracle, ntris, W, H, bounces, spp, variant):
+@pytest.mark.parametrize("ntris,W,H,bounces,spp,variant,lds", [(100000, 96, 64, 8, 2, 0, 2), (100000, 96, 64, 8, 2, 0, 0), (100000, 64, 48, 8, 2, 1, 2),
+                                                                 (1000000, 48, 48, 16, 2, 0, 2), (1000000, 48, 48, 16, 2, 0, 0), (1000000, 48, 48, 16, 2, 1, 2)])
+def test_mesh_configs_c3_c5(api, oracle, ntris, W, H, bounces, spp, variant, lds):
     """BASELINE configs 3 and 5 (MESH-100k at 8 bounces, MESH-1M at 16 bounces: SURVEY 8d synthetic
     displaced-grid meshes inside the Cornell walls) at frame sizes the oracle finishes in seconds."""
     from opencl_path_tracer_amd import scenes
@@ -435,10 +433,12 @@ def test_mesh_configs_c3_c5(api, oracle, ntris, W, H, bounces, spp, variant):
     osc = oracle.load_scene(spec)
     sc = api.Scene(W, H).load(spec)
     sc.set_option("variant", variant)
+    sc.set_option("lds_scene", lds)               # 2: treelet staged in LDS (default), 0: L1/L2 only
+    assert sc.stat("node_mode") == (2 if lds else 1) and sc.stat("treelet_nodes") > 500
     sc.iterations = bounces
     sc.render(spp)
     fr, segs = oracle_render(oracle, osc, spec, W, H, bounces, spp)
-    check(sc, fr, "mesh %d" % ntris)
+    check(sc, fr, "mesh %d lds_scene %d" % (ntris, lds))
     assert sc.stat("segments") == segs
 
 
@@ -464,19 +464,6 @@ def test_4k_frame_properties_c4(api, cb_spec):
         x_c ^= np.bitwise_xor.reduce(tc.view(np.uint32).reshape(-1))
         del t
     assert x_r == np.bitwise_xor.reduce(ra.view(np.uint32)) and x_c == np.bitwise_xor.reduce(ca.view(np.uint32).reshape(-1))
-
-
-def test_strided_pixel_map(api, oracle, cb_spec, cb_oracle_scene):
-    """pixel_map = 1 only changes which lane owns which pixel."""
-    W, H = 70, 45
-    for rank, world in ((0, 1), (1, 3)):
-        sc = api.Scene(W, H, rank=rank, world=world).load(cb_spec)
-        sc.set_option("pixel_map", 1)
-        sc.iterations = 6
-        sc.render(3)
-        fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 6, 3)
-        ids = sc.local_pixel_ids()
-        assert same_bits(sc.read_colors()[:, :3], fr.colors()[ids, :3]) and np.array_equal(sc.read_rnds(), fr.rnds()[ids])
 
 
 @pytest.mark.parametrize("chunk,W,H,bounces,spp", [(1, 96, 72, 8, 5), (2, 50, 37, 5, 7), (4, 256, 256, 4, 16), (3, 1, 1, 4, 5), (2, 33, 65, 0, 4)])
@@ -510,20 +497,6 @@ def test_chained_passes_full_size_stress(api, cb_spec):
         b.render(12)
         assert same_bits(ca, b.read_colors()) and np.array_equal(ra, b.read_rnds())
         del b
-
-
-@pytest.mark.parametrize("tv", [1, 2, 4, 9])
-def test_traversal_schedules_identical(api, oracle, cb_spec, cb_oracle_scene, tv):
-    """Scheduling variants of the render kernel (1 wave-voting, n >= 2 sliced traversal with n-1
-    rounds per trip) only reorder work between lanes: results stay bit-identical."""
-    W, H = 80, 56
-    sc = api.Scene(W, H).load(cb_spec)
-    sc.set_option("traversal", tv)
-    sc.iterations = 8
-    sc.render(3)
-    fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 8, 3)
-    check(sc, fr, "traversal=%d" % tv)
-    assert sc.stat("segments") == segs
 
 
 def test_closest_hit_unit_level(api, oracle, cb_spec, cb_oracle_scene):
@@ -677,10 +650,74 @@ def test_closest_hit_unit_level_mesh(api, oracle):
     ot0 = np.where(h0["t"] > 0, h0["t"], np.float32(-1))
     ot2 = np.where(h2["t"] > 0, h2["t"], np.float32(-1))
     assert same_bits(ot0, ot2)
-    for policy in (0, 4):
+    for policy, lds, treelet in ((0, 2, -1), (0, 2, 64), (0, 0, -1), (4, 2, -1), (4, 0, -1)):
         sc = api.Scene(16, 16)
         sc.set_option("bvh_policy", policy)
+        sc.set_option("treelet", treelet)
+        sc.set_option("lds_scene", lds)
         sc.load(spec)
+        assert sc.stat("node_mode") == (2 if lds else 1)
         t, tri = sc.debug_closest_hit(rays)
-        assert same_bits(t, ot2), "bvh_policy %d" % policy
+        assert same_bits(t, ot2), "bvh_policy %d lds_scene %d treelet %d" % (policy, lds, treelet)
         assert (tri >= 0).sum() > 2500
+
+
+@pytest.mark.parametrize("W,H,world,rb", [(64, 52, 2, 8), (40, 100, 3, 16), (24, 37, 8, 8)])
+def test_deinterleave_kernel(api, W, H, world, rb):
+    """The de-interleave kernel of pt_gather_frame on a synthetic all-gather buffer whose every pixel
+    names its (rank, local index): the assembled frame must name, for every global pixel, the rank that
+    owns it and its position in that rank's slab (pt_local_pixel_ids of that rank)."""
+    slab = api.Scene(W, H, device=None, rank=0, world=world, rows_per_block=rb).slab_pixels
+    g = np.zeros((world * slab, 4), dtype=np.float32)
+    g[:, 0] = np.repeat(np.arange(world), slab)
+    g[:, 1] = np.tile(np.arange(slab), world)
+    g[:, 2] = -1.0
+    sc = api.Scene(W, H, rank=world - 1, world=world, rows_per_block=rb)
+    frame = sc.debug_deinterleave(g)
+    for r in range(world):
+        ids = api.Scene(W, H, device=None, rank=r, world=world, rows_per_block=rb).local_pixel_ids()
+        assert (frame[ids, 0] == r).all() and np.array_equal(frame[ids, 1], np.arange(ids.size, dtype=np.float32))
+    assert (frame[:, 2] == -1.0).all()
+
+
+def test_gather_frame_through_rccl_one_rank(api, oracle, cb_spec, cb_oracle_scene):
+    """pt_comm_unique_id / pt_comm_init / pt_gather_frame with a one-rank communicator: the whole C-ABI
+    exchange path (librccl bound at run time, ncclAllGather on the context's stream, de-interleave kernel)
+    runs for real; with one rank the assembled frame must equal the colors buffer.  N > 1 needs N GPUs: the
+    index math is covered by test_deinterleave_kernel and tests/test_frame_io.py."""
+    W, H = 64, 40
+    sc = api.Scene(W, H, rank=0, world=1, rows_per_block=8).load(cb_spec)
+    sc.iterations = 4
+    sc.render(2)
+    sc.comm_init(api.comm_unique_id())
+    sc.gather_frame()
+    assert sc.device_frame() != sc.device_colors()
+    fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 4, 2)
+    assert same_bits(sc.read_frame()[:, :3], fr.colors()[:, :3])
+    with pytest.raises(api.PtError):
+        sc.comm_init(api.comm_unique_id())                       # a context has one communicator
+    t = api.Scene(W, H, rank=1, world=2, rows_per_block=8).load(cb_spec)
+    with pytest.raises(api.PtError) as e:
+        t.gather_frame()                                         # tiled context without a communicator
+    assert e.value.code == api.PT_EINVAL
+
+
+def test_image_files_of_a_render(api, cb_spec, tmp_path):
+    """pt_write_pfm = the HDR colors (the parity target) bit for bit; pt_write_ppm = the Reinhard/sRGB
+    resolve (prog.cl:247-269) quantised to 8 bits with the black pixels' NaN written as 0."""
+    W, H = 48, 32
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.iterations = 4
+    sc.render(4)
+    pfm, ppm = str(tmp_path / "f.pfm"), str(tmp_path / "f.ppm")
+    sc.write_pfm(pfm)
+    sc.write_ppm(ppm, 0)
+    raw = open(pfm, "rb").read().split(b"\n", 3)
+    assert raw[0] == b"PF" and raw[1] == b"%d %d" % (W, H)
+    assert np.array_equal(np.frombuffer(raw[3], dtype="<u4").reshape(H * W, 3), sc.read_colors()[:, :3].copy().view(np.uint32))
+    ldr = sc.resolve_ldr(0)[:, :3].reshape(H, W, 3)
+    assert np.isnan(ldr).any()                                   # the open side of the box: black pixels
+    exp = np.where(ldr > 0, np.minimum(ldr, 1.0), 0.0)
+    exp8 = np.rint(exp * 255.0).astype(np.uint8)[::-1]
+    raw = open(ppm, "rb").read().split(b"\n", 3)
+    assert raw[0] == b"P6" and np.array_equal(np.frombuffer(raw[3], dtype=np.uint8).reshape(H, W, 3), exp8)

@@ -45,13 +45,71 @@ def test_bvh_structure(api, cb_spec):
     mati = np.concatenate([m for _, m in cb_spec.objects])
     assert np.array_equal(meta[:, 1], mati[orig])
     assert np.array_equal(meta[:, 0], sc.debug_encounter_rank(1932)[orig])
-    # with LDS staging requested, the builder picks fatter leaves so that the Cornell box fits the
-    # LDS of one CU next to the traversal stacks
-    sc.set_option("lds_scene", 1)
-    nodes2, tris2, _, orig2 = sc.debug_bvh()
-    assert sorted(orig2.tolist()) == list(range(1932))
-    bvh_check.validate_structure(nodes2, tris2, 1932)
-    assert nodes2.nbytes + tris2.nbytes + 16 * 4 * 256 <= 160 * 1024 < nodes.nbytes + tris.nbytes + 16 * 4 * 256
+    assert sc.stat("node_mode") == 0 and sc.stat("treelet_nodes") == 0      # 941 nodes: the whole tree is staged in LDS
+
+
+@pytest.mark.parametrize("ntris,want", [(6000, -1), (100000, -1), (100000, 300), (100000, 0)])
+def test_treelet_reindexing(api, ntris, want):
+    """Trees too large for LDS: the T nodes with the largest boxes are renumbered
+    to [0, T) -- a connected top of the tree containing the root -- and the tree stays a valid BVH over
+    all triangles.  T = what fits next to one 1,024-thread workgroup's stacks (or the requested count)."""
+    from opencl_path_tracer_amd import scenes
+    spec = scenes.displaced_grid_mesh(ntris)
+    sc = api.Scene(16, 16, device=None)
+    sc.set_option("treelet", want)
+    sc.load(spec)
+    nodes, tris, meta, orig = sc.debug_bvh()
+    T = int(sc.stat("treelet_nodes"))
+    assert sorted(orig.tolist()) == list(range(spec.ntris))
+    bvh_check.validate_structure(nodes, tris, spec.ntris)
+    if want == 0:
+        assert T == 0 and sc.stat("node_mode") == 1
+        return
+    assert sc.stat("node_mode") == 2
+    depth = int(sc.stat("bvh_depth"))
+    entries = min(36, ((depth + 4) + 1) & ~1)
+    cap = (160 * 1024 - 8 * 1024 - entries * 4 * 1024) // 64
+    assert T == min(cap if want < 0 else min(cap, want), nodes.shape[0]) and T >= 2
+    left, right = nodes[:, 12].view(np.int32), nodes[:, 13].view(np.int32)
+    parent = np.full(nodes.shape[0], -1)
+    for i in range(nodes.shape[0]):
+        for c in (left[i], right[i]):
+            if c >= 0:
+                assert parent[c] == -1
+                parent[c] = i
+    assert parent[0] == -1 and (parent[1:] >= 0).all()
+    assert (parent[1:T] < T).all(), "the treelet is not closed under 'parent'"
+    # largest boxes first: no node outside the treelet whose parent is inside has a larger box than the
+    # smallest treelet node
+    lo = np.minimum(nodes[:, [0, 4, 8]], nodes[:, [2, 6, 10]])
+    hi = np.maximum(nodes[:, [1, 5, 9]], nodes[:, [3, 7, 11]])
+    d = (hi - lo).astype(np.float32)
+    area = d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]
+    frontier = [i for i in range(T, nodes.shape[0]) if parent[i] < T]
+    if frontier:
+        assert area[frontier].max() <= area[:T].min()
+
+
+def test_scene_size_cap(api):
+    """Device offsets are 32-bit (packet index * 48, node index << 6): pt_add_triangles refuses more than
+    2^26 triangles before it reads anything."""
+    sc = api.Scene(8, 8, device=None)
+    one = api.Triangle((0, 0, 0), (1, 0, 0), (0, 1, 0), 0)
+    with pytest.raises(api.PtError) as e:
+        api.LIB.pt_add_triangles.argtypes  # noqa: B018  (signature set by api._load)
+        sc._ck(api.LIB.pt_add_triangles(sc._h, one.ctypes.data, (1 << 26) + 1))
+    assert e.value.code == api.PT_EINVAL and "2^26" in str(e.value)
+    sc._ck(api.LIB.pt_add_triangles(sc._h, one.ctypes.data, 1))           # the context is still usable
+
+
+def test_option_validation(api):
+    sc = api.Scene(8, 8, device=None)
+    for key, bad in (("variant", 2), ("lds_scene", 1), ("lds_scene", 3), ("treelet", -2), ("treelet", 5000), ("chunk_spp", -2),
+                     ("sah_visit_cost", -1), ("debug_repeat", -1), ("debug_repeat", 100000), ("bvh_policy", 5),
+                     ("block", 256), ("min_waves", 4), ("traversal", 1), ("pixel_map", 1), ("no_such_option", 0)):
+        with pytest.raises(api.PtError) as e:
+            sc.set_option(key, bad)
+        assert e.value.code == api.PT_EINVAL, key
 
 
 def test_bvh_never_culls_a_real_hit(api, oracle, cb_spec, cb_oracle_scene):

@@ -8,11 +8,13 @@ from opencl_path_tracer_amd import api, scenes  # noqa: E402
 
 def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
     sc = api.Scene(W, H)
-    if "bvh_policy" in opts:
-        sc.set_option("bvh_policy", opts["bvh_policy"])
+    pre = ("bvh_policy", "treelet")                 # options the upload depends on
+    for k in pre:
+        if k in opts:
+            sc.set_option(k, opts[k])
     sc.load(spec)
     for k, v in opts.items():
-        if k != "bvh_policy":
+        if k not in pre:
             sc.set_option(k, v)
     sc.set_option("timing", 1)
     sc.set_option("count_work", 1 if count else 0)
@@ -33,8 +35,8 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
         print("   per-tile lane balance (lane segments / 64 x busiest lane): %.1f%%" % (100 * segs / max(sc.stat("tile_lane_steps"), 1)))
         extra = "  nodes/seg=%.2f tris/seg=%.2f | per wave-segment: node body x%.1f (util %.0f%%), tri body x%.1f (util %.0f%%)" % (
             nv / segs, tt / segs, wn / wsegs, 100 * nv / (64 * wn), wt / wsegs, 100 * tt / (64 * wt))
-    print("%dx%d b%d spp%d %-45s nodes=%d lds_bytes=%6d: %8.1f Msamples/s (kernel %8.1f)  dbar=%.3f  Mseg/s=%.1f%s" % (
-        W, H, bounces, spp, str(opts), sc.stat("bvh_nodes"), sc.stat("lds_bytes"), samples / dt / 1e6, samples / kms / 1e3, segs / samples, segs / kms / 1e3, extra), flush=True)
+    print("%dx%d b%d spp%d %-34s nodes=%d mode=%d treelet=%d lds_bytes=%6d: %8.1f Msamples/s (kernel %8.1f)  dbar=%.3f  Mseg/s=%.1f%s" % (
+        W, H, bounces, spp, str(opts), sc.stat("bvh_nodes"), sc.stat("node_mode"), sc.stat("treelet_nodes"), sc.stat("lds_bytes"), samples / dt / 1e6, samples / kms / 1e3, segs / samples, segs / kms / 1e3, extra), flush=True)
 
 
 def checksum(W, H, bounces, spp, spec, **opts):
@@ -50,12 +52,33 @@ def checksum(W, H, bounces, spp, spec, **opts):
 
 
 if __name__ == "__main__":
-    cb = scenes.cornell_box()
-    run(256, 256, 4, 64, cb, reps=4)
-    m100 = scenes.displaced_grid_mesh(100000)
-    run(1920, 1080, 8, 16, m100, reps=2)
-    run(1920, 1080, 8, 16, m100, reps=2, variant=1)
-    run(3840, 2160, 8, 16, cb, reps=2)
-    m1m = scenes.displaced_grid_mesh(1000000)
-    run(1920, 1080, 16, 8, m1m, reps=2)
-    run(1920, 1080, 16, 8, m1m, reps=2, variant=1)
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--count", action="store_true", help="also the counting kernel instance (lane utilisation)")
+    ap.add_argument("--what", default="cb,mesh100k,mesh1m")
+    args = ap.parse_args()
+    what = args.what.split(",")
+    if "cb" in what:
+        cb = scenes.cornell_box()
+        run(1920, 1080, 8, 64, cb, reps=3)
+        run(1920, 1080, 8, 64, cb, reps=3, lds_scene=0)
+        run(1920, 1080, 8, 16, cb, reps=2, variant=1)
+        run(1920, 1080, 8, 16, cb, reps=2, variant=1, lds_scene=0)
+        if args.count:
+            run(1920, 1080, 8, 16, cb, reps=1, count=True)
+    if "c1c4" in what:
+        cb = scenes.cornell_box()
+        run(256, 256, 4, 64, cb, reps=4)
+        run(3840, 2160, 8, 16, cb, reps=2)
+    for name, n, b, spp in (("mesh100k", 100000, 8, 16), ("mesh1m", 1000000, 16, 8)):
+        if name not in what:
+            continue
+        m = scenes.displaced_grid_mesh(n)
+        run(1920, 1080, b, spp, m, reps=2)
+        run(1920, 1080, b, spp, m, reps=2, lds_scene=0)
+        run(1920, 1080, b, spp, m, reps=2, treelet=256)
+        run(1920, 1080, b, spp, m, reps=2, variant=1)
+        run(1920, 1080, b, spp, m, reps=2, variant=1, lds_scene=0)
+        if args.count:
+            run(1920, 1080, b, spp, m, reps=1, count=True)
+            run(1920, 1080, b, spp, m, reps=1, count=True, lds_scene=0)
