@@ -9,14 +9,27 @@ to 8 segments.  One "step" = one pass of the hot path (gen_ray + trace_ray, fuse
 N > 1 (launched by torch.distributed.run, one process per GPU): the frame is tiled in
 interleaved 8-row blocks over the ranks (strong scaling: the frame is fixed), every rank
 renders its own pixels with no communication, and the timed region ends with ONE RCCL
-all-gather of the radiance slabs + de-interleave on every rank.
+all-gather of the radiance slabs + de-interleave on every rank -- issued through the
+library's own C ABI (pt_comm_init / pt_gather_frame: ncclAllGather on the render stream + a
+de-interleave kernel); torch.distributed only launches the processes, carries the 128-byte
+communicator id and reduces the timing scalars.  --exchange torch uses round 1's
+all_gather_into_tensor + index_copy_ instead.
 
 The timed region starts with scene, seeds and framebuffer resident in HBM and is bracketed by
 barrier + torch.cuda.synchronize(); the time is the max over ranks.  Rank 0 prints ONE JSON line.
 
-Extra objects: "roofline" (algorithmic HBM bytes of SURVEY 8(d) / HIP-event kernel time vs the
-8 TB/s peak) and "cpu_baseline" (the CPU oracle = port of the reference path, timed on this
-host's cores on a bounded sample of the same workload; rank 0, N = 1 only).
+Extra objects:
+  "roofline"       SURVEY 8(d)'s algorithmic HBM bytes of the kernel that runs / HIP-event kernel time vs
+                   the 8 TB/s peak.  Megakernel (default): 40 B/sample (colors 16 B R + 16 B W, rnds 4 B R +
+                   4 B W) -- the path state never leaves the registers, so this fraction is tiny and says
+                   only that the kernel is NOT HBM bound; wavefront: 32 B/sample + 200 B/segment.
+  "roofline_valu"  what bounds the megakernel: VALU issue.  VALU instructions per SIMD-cycle (peak 0.5: one
+                   wave64 instruction per 2 cycles) and the active-lane fraction, from the tracked rocprofv3
+                   SQ-counter summary (profiles/counters.json, written by tools/pmc_record.py); "stale" tells
+                   whether the kernel sources changed since it was measured.  instructions-per-launch x live
+                   launch count / live kernel time is re-derived with THIS run's HIP-event time.
+  "cpu_baseline"   the CPU oracle (port of the reference path) timed on this host's cores on a bounded
+                   sample of the same workload; rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -37,8 +50,11 @@ from opencl_path_tracer_amd import api, scenes  # noqa: E402
 WIDTH, HEIGHT, BOUNCES = 1920, 1080, 8
 ROWS_PER_BLOCK = 8
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
-BYTES_PER_SEGMENT = 200.0        # 92 B state R + 92 B W + 8 B hit W + 8 B R
-BYTES_PER_SAMPLE = 32.0          # colors 16 B R + 16 B W
+BYTES_PER_SEGMENT = 200.0        # SURVEY 8(d), wavefront: 92 B state R + 92 B W + 8 B hit W + 8 B R
+BYTES_PER_SAMPLE = 32.0          # SURVEY 8(d), wavefront: colors 16 B R + 16 B W
+MEGA_BYTES_PER_SAMPLE = 40.0     # SURVEY 8(d), megakernel: colors RMW + seed RMW
+VALU_PEAK_PER_SIMD_CYCLE = 0.5   # MI355X_MICROARCH.md: v_fma_f32 (wave64) 2 cycles on a SIMD
+N_SIMD = 1024                    # 256 CUs x 4
 
 
 def parse():
@@ -50,8 +66,8 @@ def parse():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--bounces", type=int, default=BOUNCES)
-    ap.add_argument("--lds-scene", type=int, default=-1, help="-1 library default, 0/1 force")
-    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--lds-scene", type=int, default=-1, help="-1 library default, 0 nodes through L1/L2, 2 staged in LDS")
+    ap.add_argument("--exchange", choices=["cabi", "torch"], default="cabi", help="N > 1: frame assembly through pt_gather_frame (default) or torch.distributed")
     ap.add_argument("--variant", type=int, default=0, help="0 megakernel (default, fastest), 1 wavefront (stream-compacted)")
     ap.add_argument("--no-variants", action="store_true", help="skip the untimed side measurement of the other variant")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -87,6 +103,31 @@ def cpu_baseline(width, height, bounces, target_s):
             "sample": "Cornell box %dx%d, %d bounces, %d spp (full frame), oracle/pt_oracle.c mode 0, %.1f s" % (width, height, bounces, spp, t1)}
 
 
+def kernel_source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pt_device.hpp", "pt_kernels.hip", "pt_internal.hpp"):
+        h.update(open(os.path.join(ROOT, "opencl_path_tracer_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def tracked_counters(W, H, B, spp):
+    """rocprofv3 PMC summary of the same launch shape (tools/pmc_record.py), or None.  `stale` = the kernel
+    sources are not the ones it was measured with."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        tj = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    c = tj.get("cornell_%dx%d_b%d_spp%d" % (W, H, B, spp))
+    if not c:
+        return None
+    c = dict(c)
+    c["stale"] = c.get("kernel_source_sha") != kernel_source_sha()
+    c["source"] = "profiles/counters.json <- " + c.get("source", "?")
+    return c
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -115,8 +156,6 @@ def main():
     sc.iterations = B
     if args.lds_scene >= 0:
         sc.set_option("lds_scene", args.lds_scene)
-    if args.block:
-        sc.set_option("block", args.block)
     sc.set_option("variant", args.variant)
     sc.set_option("timing", 1)
 
@@ -141,7 +180,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    use_cabi = world > 1 and args.exchange == "cabi" and not args.rehearse_on_one_gpu
+    if use_cabi:          # the library's own RCCL communicator; torch only carries the 128-byte id
+        box = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        sc.comm_init(box[0])
+
     def exchange():
+        if use_cabi:
+            sc.gather_frame()           # ncclAllGather + de-interleave kernel on the render stream
+            return None
         src = slab.to(comm_dev) if (world > 1 and comm_dev != dev) else slab
         return exchange_frame(src, tmap, scatter_index, gathered, frame)
 
@@ -191,28 +239,25 @@ def main():
     segs, samples, kms_sum, launches = [float(x) for x in stats.tolist()]
     total_spp = args.steps * args.spp_per_step
     assert samples == float(W) * H * total_spp, (samples, W * H * total_spp)
-    checksum = float(out[:, :3].double().sum().item())
+    if use_cabi:
+        checksum = float(sc.read_frame()[:, :3].astype(np.float64).sum())
+    else:
+        checksum = float(out[:, :3].double().sum().item())
 
     if rank == 0:
         dbar = segs / samples
         value = samples / dt / 1e6
-        # dominant kernel: k_render.  Algorithmic bytes per launch / mean launch time.
+        # dominant kernel: k_render (or wf_intersect).  Algorithmic bytes per launch / mean launch time.
         launches_per_rank = launches / world
+        wavefront_model_bytes = (BYTES_PER_SAMPLE + BYTES_PER_SEGMENT * dbar) * (samples / launches)
         if args.variant == 0:
-            bytes_per_launch = (BYTES_PER_SAMPLE + BYTES_PER_SEGMENT * dbar) * (samples / launches)
+            bytes_per_launch = MEGA_BYTES_PER_SAMPLE * (samples / launches)
         else:   # wf_intersect alone: 32 B ray read + 8 B hit record written per ray of the launch
             bytes_per_launch = 40.0 * (segs / launches)
         mean_launch_ms = (kms_sum / world) / launches_per_rank
         achieved = bytes_per_launch / (mean_launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and world == 1:
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("config") == "%dx%d_b%d_spp%d" % (W, H, B, args.spp_per_step):
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        counters = tracked_counters(W, H, B, args.spp_per_step) if world == 1 and args.variant == 0 else None
+        traffic = counters["hbm_bytes_per_launch"] if counters and not counters["stale"] else None
         line = {
             "metric": "Msamples/s (whole node) at 1920x1080, 8-bounce Cornell box",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -227,8 +272,18 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_render" if args.variant == 0 else "wf_intersect", "mean_launch_ms": mean_launch_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "model": "SURVEY 8(d): megakernel 40 B/sample (path state stays in registers)" if args.variant == 0 else "wf_intersect: 40 B/ray",
+                         "wavefront_model_frac": wavefront_model_bytes / (mean_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if counters is not None:
+            # the bound the megakernel actually has: VALU issue, with this run's kernel time
+            ipc = counters["valu_insts_per_launch"] / N_SIMD / (mean_launch_ms * 1e-3 * counters["shader_clock_hz"])
+            line["roofline_valu"] = {"bound": "valu_issue", "achieved": ipc, "peak": VALU_PEAK_PER_SIMD_CYCLE,
+                                     "unit": "VALU instructions per SIMD-cycle", "frac": ipc / VALU_PEAK_PER_SIMD_CYCLE,
+                                     "active_lane_fraction": counters["active_lane_fraction"],
+                                     "valu_insts_per_launch": counters["valu_insts_per_launch"],
+                                     "source": counters["source"], "measured_at": counters["measured_at"], "stale": counters["stale"]}
         if other is not None:
             line["other_variant"] = other
         if world == 1 and not args.no_cpu_baseline:

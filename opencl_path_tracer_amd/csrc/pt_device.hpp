@@ -269,6 +269,7 @@ struct LaneStack {
 struct WorkCount {
     unsigned nodes, tris;     // per-lane visits / tests
     unsigned wnodes, wtris;   // wave-level executions of the two bodies (counted by the first active lane)
+    unsigned wshade, wtrips, wrounds;   // wave-level executions of shade_hit, of the segment loop body, of Trav::round
 };
 PT_DEV bool first_active_lane() {
     const unsigned long long m = __ballot(1);
@@ -315,9 +316,12 @@ struct Trav {
     PT_DEV static int leaf_bits(int c) { return kRef16 ? (c & 0x7fff) : ~c; }
 
     PT_DEV void begin(f3 P_, f3 D_, const LaneStack<StackT> stk) {
-        P = P_;
-        D = D_;
-        inv = mk(__builtin_amdgcn_rcpf(D_.x), __builtin_amdgcn_rcpf(D_.y), __builtin_amdgcn_rcpf(D_.z));
+        setup(P_, D_);
+        restart(stk);
+    }
+    // the traversal state proper: {best_t, best, tos, cur} (+ the stack itself); everything setup() computes can
+    // be recomputed from the ray, which is what lets a suspended traversal resume from four saved values
+    PT_DEV void restart(const LaneStack<StackT> stk) {
         best_t = __builtin_inff();
         best = -1;
         tos = reinterpret_cast<char*>(stk.base);
@@ -326,6 +330,11 @@ struct Trav {
         cur = 0;        // the root is always an interior node
         k = 0;
         pend = 0;
+    }
+    PT_DEV void setup(f3 P_, f3 D_) {
+        P = P_;
+        D = D_;
+        inv = mk(__builtin_amdgcn_rcpf(D_.x), __builtin_amdgcn_rcpf(D_.y), __builtin_amdgcn_rcpf(D_.z));
         onx = __float_as_int(inv.x) < 0 ? 8 : 0;
         ony = __float_as_int(inv.y) < 0 ? 24 : 16;
         onz = __float_as_int(inv.z) < 0 ? 40 : 32;
@@ -717,7 +726,7 @@ PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<type
 // no single address sees more than a few dozen atomics per launch (one address saturates at
 // ~88 atomics/us on MI355X, which cost a 32k-wave launch ~0.4 ms when every wave hit one word)
 PT_DEV void stat_add(const RenderParams& p, int slot, unsigned long long v) {
-    atomicAdd(&p.stats[(size_t)((blockIdx.x + blockIdx.y * 37u) % kStatRows) * 8 + slot], v);
+    atomicAdd(&p.stats[(size_t)((blockIdx.x + blockIdx.y * 37u) % kStatRows) * kStatCols + slot], v);
 }
 
 PT_DEV unsigned long long wave_sum(unsigned long long v) {

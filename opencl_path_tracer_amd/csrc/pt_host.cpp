@@ -102,6 +102,8 @@ struct pt_context {
     int chunk_spp = -1;   // persistent megakernel work items: > 0 (pass, tile) items of that many samples, 0 whole
                           // tiles, -1 automatic (4 when the context has clearly more tiles than resident waves)
     int sah_visit_cost = 10;   // tenths of a triangle test (option sah_visit_cost)
+    int schedule = 1;      // megakernel: 0 lockstep per sample, 1 restart + tail suspension (default: faster everywhere measured)
+    int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 24 with the whole tree in LDS, else 48)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
     int bvh_policy = 0;   // 0/1 host SAH with SAH leaf termination, 2 leaves of <= 4, 3 leaves of <= 8, 4 device LBVH
@@ -584,6 +586,9 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->chunk_spp = 0;
     p->tile_done = nullptr;
     p->n_tiles = ((ctx->W + 7) / 8) * ((ctx->local_rows + 7) / 8);
+    // measured (profiles/r02/d_*): Cornell box in LDS 16 / 24 / 32 -> 1515 / 1532 / 1526 Msamples/s (lockstep 1495);
+    // MESH-100k 32 / 40 / 48 / 56 -> 569 / 580 / 580 / 580 (lockstep 511); MESH-1M 205 at 48 (lockstep 173)
+    p->suspend_lanes = ctx->suspend_lanes >= 0 ? ctx->suspend_lanes : (p->node_mode == kNodesLds ? 24 : 48);
 }
 
 int check_ready(pt_context* ctx, const pt_camera* cam) {
@@ -747,11 +752,11 @@ int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int
     if ((e = hipMalloc((void**)&ctx->d_rays, sizeof(pt_ray) * np)) != hipSuccess) return bail("hipMalloc(rays)", e);      // main.cpp:508
     if ((e = hipMalloc((void**)&ctx->d_rnds, sizeof(int32_t) * np)) != hipSuccess) return bail("hipMalloc(rnds)", e);     // main.cpp:509
     if ((e = hipMalloc((void**)&ctx->d_colors, sizeof(float4) * nslab)) != hipSuccess) return bail("hipMalloc(colors)", e);  // main.cpp:520
-    if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * 8 * kStatRows)) != hipSuccess) return bail("hipMalloc(stats)", e);
+    if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatCols * kStatRows)) != hipSuccess) return bail("hipMalloc(stats)", e);
     if ((e = hipMalloc((void**)&ctx->d_tile_counter, 64)) != hipSuccess) return bail("hipMalloc(tile counter)", e);
     if ((e = hipMemset(ctx->d_rays, 0, sizeof(pt_ray) * np)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->d_colors, 0, sizeof(float4) * nslab)) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8 * kStatRows)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * kStatCols * kStatRows)) != hipSuccess) return bail("hipMemset", e);
     int rc = pt_seed_default(ctx);                                                                                    // main.cpp:522-527
     if (rc != PT_OK) {
         std::string msg = ctx->err;
@@ -952,6 +957,7 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
     lc->block = traversal_block(p.node_mode);
     lc->lds_bytes = traversal_lds_bytes(p, lc->block);
     lc->count_work = ctx->count_work != 0;
+    lc->schedule = ctx->schedule;
     // resident workgroups at 4 waves per SIMD: 4 x 256 threads (nodes through L1/L2), 2 x 512 (whole tree in
     // LDS), 1 x 1024 (treelet) per CU
     lc->persistent_blocks = ctx->cu_count * std::max(1, 1024 / lc->block);
@@ -1278,6 +1284,12 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "sah_visit_cost") {
         if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "sah_visit_cost: tenths of a triangle test, 0..1000");
         ctx->sah_visit_cost = (int)value;
+    } else if (k == "schedule") {
+        if (value < 0 || value > 1) return fail(ctx, PT_EINVAL, "schedule: 0 lockstep per sample, 1 restart + tail suspension");
+        ctx->schedule = (int)value;
+    } else if (k == "suspend_lanes") {
+        if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, "suspend_lanes: -1 default, 0..63");
+        ctx->suspend_lanes = (int)value;
     } else if (k == "debug_repeat") {
         if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "debug_repeat: 0..1000 extra timed launches");
         ctx->debug_repeat = (int)value;
@@ -1291,7 +1303,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (ctx->has_device) {
             PT_HIP(ctx, hipSetDevice(ctx->device));
             PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * 8 * kStatRows));
+            PT_HIP(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * kStatCols * kStatRows));
         }
         int rc = time_collect(ctx);
         if (rc != PT_OK) return rc;
@@ -1330,14 +1342,15 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out) {
         *out = ctx->kernel_ms_acc;
         return PT_OK;
     }
-    if (k == "segments" || k == "samples" || k == "node_visits" || k == "tri_tests" || k == "wave_node_steps" || k == "wave_tri_steps" || k == "tile_lane_steps") {
-        std::vector<unsigned long long> rows((size_t)8 * kStatRows);
-        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k == "segments" || k == "samples" || k == "node_visits" || k == "tri_tests" || k == "wave_node_steps" || k == "wave_tri_steps" || k == "tile_lane_steps" ||
+        k == "wave_shade_steps" || k == "wave_trips" || k == "wave_rounds") {
+        std::vector<unsigned long long> rows((size_t)kStatCols * kStatRows);
+        unsigned long long h[kStatCols] = {};
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         PT_HIP(ctx, hipMemcpy(rows.data(), ctx->d_stats, sizeof(unsigned long long) * rows.size(), hipMemcpyDeviceToHost));
         for (int r = 0; r < kStatRows; ++r)
-            for (int c = 0; c < 8; ++c) h[c] += rows[(size_t)r * 8 + c];
-        *out = (double)h[k == "segments" ? 0 : k == "samples" ? 1 : k == "node_visits" ? 2 : k == "tri_tests" ? 3 : k == "wave_node_steps" ? 4 : k == "wave_tri_steps" ? 5 : 6];
+            for (int c = 0; c < kStatCols; ++c) h[c] += rows[(size_t)r * kStatCols + c];
+        *out = (double)h[k == "segments" ? 0 : k == "samples" ? 1 : k == "node_visits" ? 2 : k == "tri_tests" ? 3 : k == "wave_node_steps" ? 4 : k == "wave_tri_steps" ? 5 : k == "tile_lane_steps" ? 6 : k == "wave_shade_steps" ? 7 : k == "wave_trips" ? 8 : 9];
         return PT_OK;
     }
     return fail(ctx, PT_EINVAL, "unknown stat: " + k);

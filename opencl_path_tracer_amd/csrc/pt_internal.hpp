@@ -47,7 +47,8 @@ constexpr int64_t kMaxTriangles = (int64_t)1 << 26;
 
 constexpr int kMaxLeaf = 4;        // triangles per leaf (<= 8 by the reference encoding)
 constexpr int kMaxDepth = 30;      // builder guarantees depth <= kMaxDepth
-constexpr int kStatRows = 256;     // statistics counters are spread over this many rows of 8
+constexpr int kStatRows = 256;     // statistics counters are spread over this many rows of kStatCols
+constexpr int kStatCols = 16;
 constexpr int kStackEntries = 36;  // upper bound of the per-lane traversal stack: sentinel + far children + one slot above the top
 
 // ---- kernel parameter block (passed by value, like `Camera` in prog.cl:292-304) ----------
@@ -59,7 +60,8 @@ struct RenderParams {
     int32_t* rnds;          // local pixels
     float4* colors;         // local pixels, float3 @ 16 B
     pt_ray* rays;           // local pixels
-    unsigned long long* stats;   // [kStatRows][8]: 0 segments, 1 samples, 2 node visits, 3 tri tests, 4/5 wave-level body runs
+    unsigned long long* stats;   // [kStatRows][kStatCols]: 0 segments, 1 samples, 2 node visits, 3 tri tests, 4/5 wave-level body runs,
+                                 // 6 tile lane steps, 7 wave-level shade runs, 8 wave-level trips of the segment loop, 9 wave-level rounds
     pt_camera cam;
     int32_t width, height;       // GLOBAL frame
     int32_t local_rows;          // rows owned by this context
@@ -74,6 +76,7 @@ struct RenderParams {
     int32_t chunk_spp;           // > 0: a work item is (pass, tile) = chunk_spp samples of a tile; passes of one
                                  // tile are chained through tile_done[] (agent-scope release / acquire)
     uint32_t* tile_done;         // [n_tiles] number of passes completed, zeroed before the launch
+    int32_t suspend_lanes;       // megakernel: leave the traversal when at most this many lanes are unfinished (0: never)
 };
 
 // ---- wavefront (stream-compacted) formulation
@@ -120,7 +123,8 @@ struct LaunchConfig {
     int block = 256;                   // traversal_block(node_mode)
     size_t lds_bytes = 0;              // traversal_lds_bytes()
     int persistent_blocks = 1 << 30;   // grid size of a persistent launch (workgroups that fit the chip)
-    bool count_work = false;           // also count node visits / triangle tests into stats[2..6]
+    bool count_work = false;           // also count node visits / triangle tests into stats[2..9]
+    int schedule = 0;                  // megakernel: 0 lockstep per sample, 1 restart + tail suspension (pt_kernels.hip)
 };
 
 // launchers (pt_kernels.hip, pt_wavefront.hip, pt_debug.hip); all asynchronous on `stream`

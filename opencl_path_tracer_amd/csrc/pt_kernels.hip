@@ -18,6 +18,7 @@
 // packets and the rest of a large tree are read through L1/L2.
 #include "pt_device.hpp"
 
+
 #include <algorithm>
 
 namespace ptamd {
@@ -39,9 +40,77 @@ __global__ void __launch_bounds__(256) k_gen_ray(RenderParams p) {
 
 // All samples [s_begin, s_end) of ONE pixel, path state in registers: nsamples x (gen_ray + trace_ray).
 // SPLIT: trace_ray alone (prog.cl:292-381) -- the ray comes from, and is left in, the rays buffer.
+//
+// Two schedules of the same per-pixel computation (what a wave executes together is the only difference;
+// tools/sim/policy_sim.py replays both on recorded traversal traces and predicts their instruction counts
+// within a few percent of the SQ counters, profiles/r02/):
+//
+//  kSchedLockstep  explicit sample loop around a bounce loop.  All lanes of a wave start a sample together and
+//                  a lane whose path ended waits for the wave's longest path.  Idle lanes cost nothing in a
+//                  VALU-issue-bound kernel, while lanes that march in step trace rays of the same generation:
+//                  the camera rays of a tile are coherent (their traversal executes the node body 10 times per
+//                  wave instead of 54), first-bounce rays still start next to each other (35).  Best schedule
+//                  for the Cornell box (whole tree in LDS): 7-11 % fewer instructions than "restart".
+//
+//  kSchedSuspend   one flat segment loop: a lane whose path ended starts its next sample at once ("restart"),
+//                  and the traversal is resumable (tail suspension).  The lanes of a wave need very different
+//                  numbers of node visits (median 6, 99th percentile 33: over half of the node-body executions
+//                  of a plain while-while loop run for <= 4 lanes), so the wave leaves the traversal as soon as
+//                  at most p.suspend_lanes lanes are still at it (and at least one has finished): the finished
+//                  lanes shade and start their next segment, the stragglers keep {best_t, best, tos, cur} and
+//                  resume in the next trip, where their remaining visits overlap with everybody's new rays.
+//                  Costs more shading executions (each for fewer lanes): a loss when VALU-bound, +13-14 % on
+//                  the latency-bound mesh scenes where every wave-level step saved is a memory round trip saved.
+enum : int { kSchedLockstep = 0, kSchedSuspend = 1 };
+
 template <bool SPLIT, int MODE, bool COUNT>
-PT_DEV void render_pixel(const RenderParams& p, const SceneView& sv, const LaneStack<typename StackOf<MODE>::type> stk, const PixelId px,
-                         int s_begin, int s_end, unsigned long long* segs, unsigned long long* samples, WorkCount* wc) {
+PT_DEV void render_pixel_lockstep(const RenderParams& p, const SceneView& sv, const LaneStack<typename StackOf<MODE>::type> stk, const PixelId px,
+                                  int s_begin, int s_end, unsigned long long* segs, unsigned long long* samples, WorkCount* wc) {
+    int seed = p.rnds[px.li];
+    f3 acc = mk(0.0f, 0.0f, 0.0f);
+    if (s_begin != 0) {                        // prog.cl:312-314: sample 0 starts from black
+        const float4 c = p.colors[px.li];
+        acc = mk(c.x, c.y, c.z);
+    }
+    const int camX = (int)p.cam.XM;
+    const float pix_x = (float)(px.gid % camX), pix_y = (float)(px.gid / camX);      // prog.cl:84-85
+    f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
+    for (int s = s_begin; s < s_end; ++s) {    // the same trip count on every lane of the wave
+        f3 fL = mk(1.f, 1.f, 1.f), fB = fL, fS = fL, fR = fL, color = mk(0.f, 0.f, 0.f);     // prog.cl:307-316
+        bool inside = false;
+        if (SPLIT) {
+            const float4* r = reinterpret_cast<const float4*>(&p.rays[px.li]);
+            const float4 a = r[0], b = r[1];
+            rP = mk(a.x, a.y, a.z);
+            rD = mk(b.x, b.y, b.z);
+        } else {
+            const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+            camera_get_ray_xy(pix_x, pix_y, p.cam, rnd1, rnd2, &rP, &rD);
+        }
+        for (int bounce = 0; bounce < p.iterations; ++bounce) {     // a lane that leaves early waits for the others
+            if (COUNT && first_active_lane()) wc->wtrips++;
+            float t;
+            const int ti = closest_hit<MODE, COUNT>(sv, rP, rD, stk, &t, wc);
+            ++*segs;
+            if (ti < 0) break;                                       // black environment, prog.cl:367-376
+            if (COUNT && first_active_lane()) wc->wshade++;
+            shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, ti, t);
+        }
+        acc = running_mean(acc, color, s);
+        ++*samples;
+    }
+    p.colors[px.li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    p.rnds[px.li] = seed;
+    if (SPLIT) {
+        float4* r = reinterpret_cast<float4*>(&p.rays[px.li]);
+        r[0] = make_float4(rP.x, rP.y, rP.z, 0.0f);
+        r[1] = make_float4(rD.x, rD.y, rD.z, 0.0f);
+    }
+}
+
+template <bool SPLIT, int MODE, bool COUNT>
+PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, const LaneStack<typename StackOf<MODE>::type> stk, const PixelId px,
+                                 int s_begin, int s_end, unsigned long long* segs, unsigned long long* samples, WorkCount* wc) {
     f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
     f3 fL = mk(1.f, 1.f, 1.f), fB = fL, fS = fL, fR = fL, color = mk(0.f, 0.f, 0.f);
     bool inside = false;
@@ -54,10 +123,16 @@ PT_DEV void render_pixel(const RenderParams& p, const SceneView& sv, const LaneS
     int s = s_begin;
     int bounce = 0;
     bool fresh = true;
+    bool traversing = false;                   // this lane holds a suspended traversal
+    Trav<MODE> tr;
+    tr.setup(rP, rD);
+    tr.restart(stk);
+    tr.idle();
     const int camX = (int)p.cam.XM;
     const float pix_x = (float)(px.gid % camX), pix_y = (float)(px.gid / camX);      // prog.cl:84-85
     for (;;) {
-        if (fresh) {                           // a lane whose path ended starts its next sample right here
+        if (COUNT && first_active_lane()) wc->wtrips++;
+        if (fresh && !traversing) {            // a lane whose path ended starts its next sample right here
             if (s == s_end) break;
             fL = mk(1.f, 1.f, 1.f);            // prog.cl:307-316
             fB = fL;
@@ -78,14 +153,27 @@ PT_DEV void render_pixel(const RenderParams& p, const SceneView& sv, const LaneS
             fresh = false;
         }
         bool finished = true;
-        if (bounce < p.iterations) {
-            float t;
-            const int ti = closest_hit<MODE, COUNT>(sv, rP, rD, stk, &t, wc);
-            ++*segs;
-            if (ti >= 0) {
-                shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, ti, t);
-                ++bounce;
-                finished = (bounce >= p.iterations);
+        if (traversing || bounce < p.iterations) {
+            tr.setup(rP, rD);                  // direction-dependent constants: recomputed for new and resumed rays alike
+            if (!traversing) tr.restart(stk);
+            for (;;) {
+                if (COUNT && first_active_lane()) wc->wrounds++;
+                tr.template round<COUNT>(sv, wc);
+                const unsigned long long unfinished = __ballot(!tr.done());
+                if (unfinished == 0) break;
+                if (__popcll(unfinished) <= p.suspend_lanes && __ballot(tr.done()) != 0) break;
+            }
+            traversing = !tr.done();
+            if (traversing) {
+                finished = false;
+            } else {
+                ++*segs;
+                if (tr.best >= 0) {
+                    if (COUNT && first_active_lane()) wc->wshade++;
+                    shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, tr.best, tr.best_t);
+                    ++bounce;
+                    finished = (bounce >= p.iterations);
+                }
             }
         }
         if (finished) {
@@ -117,7 +205,7 @@ PT_DEV void render_pixel(const RenderParams& p, const SceneView& sv, const LaneS
 //    reach this wave -- possibly on another XCD -- through an agent-scope release (producer: stores,
 //    L2 write-back, tile_done[tile] = pass + 1) and acquire (consumer: poll, L1 invalidate, loads).
 //    The host guarantees n_pass * n_tiles + (resident waves) < 2^31 (pt_render).
-template <bool SPLIT, int MODE, int BLOCK, bool COUNT>
+template <bool SPLIT, int MODE, int BLOCK, bool COUNT, int SCHED>
 __global__ void __launch_bounds__(BLOCK, 4) k_render(RenderParams p) {
     LaneStack<typename StackOf<MODE>::type> stk;
     SceneView sv;
@@ -127,6 +215,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_render(RenderParams p) {
     wc.tris = 0;
     wc.wnodes = 0;
     wc.wtris = 0;
+    wc.wshade = 0;
+    wc.wtrips = 0;
+    wc.wrounds = 0;
     const bool lane0 = (threadIdx.x & 63) == 0;
     const bool chained = p.tile_counter != nullptr && p.chunk_spp > 0;
     const int n_pass = chained ? (p.nsamples + p.chunk_spp - 1) / p.chunk_spp : 1;
@@ -155,7 +246,10 @@ __global__ void __launch_bounds__(BLOCK, 4) k_render(RenderParams p) {
         const int s_begin = p.first_sample + (chained ? pass * p.chunk_spp : 0);
         const int s_end = chained ? min(s_begin + p.chunk_spp, p.first_sample + p.nsamples) : p.first_sample + p.nsamples;
         const PixelId px = pixel_of_wave(p, tile);
-        if (px.li >= 0) render_pixel<SPLIT, MODE, COUNT>(p, sv, stk, px, s_begin, s_end, &segs, &samples, &wc);
+        if (px.li >= 0) {
+            if (SCHED == kSchedLockstep) render_pixel_lockstep<SPLIT, MODE, COUNT>(p, sv, stk, px, s_begin, s_end, &segs, &samples, &wc);
+            else render_pixel_suspend<SPLIT, MODE, COUNT>(p, sv, stk, px, s_begin, s_end, &segs, &samples, &wc);
+        }
         if (COUNT) {      // segment-steps the wave executed for this item = 64 x the busiest lane's segments
             unsigned long long mx = segs - segs_before_item;
             for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned long long)__shfl_down(mx, off, 64));
@@ -174,12 +268,16 @@ __global__ void __launch_bounds__(BLOCK, 4) k_render(RenderParams p) {
     if (COUNT) {
         const unsigned long long wn = wave_sum((unsigned long long)wc.nodes), wt = wave_sum((unsigned long long)wc.tris);
         const unsigned long long wwn = wave_sum((unsigned long long)wc.wnodes), wwt = wave_sum((unsigned long long)wc.wtris);
+        const unsigned long long wsh = wave_sum((unsigned long long)wc.wshade), wtr = wave_sum((unsigned long long)wc.wtrips), wro = wave_sum((unsigned long long)wc.wrounds);
         if (lane0 && p.stats) {
             stat_add(p, 2, wn);
             stat_add(p, 3, wt);
             stat_add(p, 4, wwn);
             stat_add(p, 5, wwt);
             stat_add(p, 6, item_lane_steps);
+            stat_add(p, 7, wsh);
+            stat_add(p, 8, wtr);
+            stat_add(p, 9, wro);
         }
     }
     if (lane0 && p.stats) {
@@ -269,14 +367,14 @@ hipError_t launch_gen_ray(const RenderParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <bool SPLIT, int MODE, int BLOCK, bool COUNT>
+template <bool SPLIT, int MODE, int BLOCK, bool COUNT, int SCHED>
 static hipError_t launch_one(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
     const int waves = n_waves(p);
     if (waves == 0) return hipSuccess;
     constexpr int wpb = BLOCK / 64;
     int blocks = (waves + wpb - 1) / wpb;
     if (p.tile_counter) blocks = std::min(blocks, lc.persistent_blocks);
-    auto kern = k_render<SPLIT, MODE, BLOCK, COUNT>;
+    auto kern = k_render<SPLIT, MODE, BLOCK, COUNT, SCHED>;
     if (lc.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc.lds_bytes);
         if (e != hipSuccess) return e;
@@ -285,20 +383,23 @@ static hipError_t launch_one(const RenderParams& p, const LaunchConfig& lc, hipS
     return hipGetLastError();
 }
 
-template <bool SPLIT, bool COUNT>
+template <bool SPLIT, bool COUNT, int SCHED>
 static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
     if (lc.block != traversal_block(p.node_mode)) return hipErrorInvalidValue;
     switch (p.node_mode) {
-    case kNodesLds: return launch_one<SPLIT, kNodesLds, 512, COUNT>(p, lc, stream);
-    case kNodesGlobal: return launch_one<SPLIT, kNodesGlobal, 256, COUNT>(p, lc, stream);
-    case kNodesTreelet: return launch_one<SPLIT, kNodesTreelet, 1024, COUNT>(p, lc, stream);
+    case kNodesLds: return launch_one<SPLIT, kNodesLds, 512, COUNT, SCHED>(p, lc, stream);
+    case kNodesGlobal: return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED>(p, lc, stream);
+    case kNodesTreelet: return launch_one<SPLIT, kNodesTreelet, 1024, COUNT, SCHED>(p, lc, stream);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) { return launch_render_t<true, false>(p, lc, stream); }
+// the split API traces one sample per launch: the two schedules coincide, one instance suffices
+hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) { return launch_render_t<true, false, kSchedLockstep>(p, lc, stream); }
 hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
-    return lc.count_work ? launch_render_t<false, true>(p, lc, stream) : launch_render_t<false, false>(p, lc, stream);
+    if (lc.schedule == kSchedLockstep)
+        return lc.count_work ? launch_render_t<false, true, kSchedLockstep>(p, lc, stream) : launch_render_t<false, false, kSchedLockstep>(p, lc, stream);
+    return lc.count_work ? launch_render_t<false, true, kSchedSuspend>(p, lc, stream) : launch_render_t<false, false, kSchedSuspend>(p, lc, stream);
 }
 
 hipError_t launch_resolve_reinhard(const float4* colors, float4* out, int64_t n, hipStream_t stream) {

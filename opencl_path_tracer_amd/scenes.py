@@ -143,3 +143,54 @@ def displaced_grid_mesh(ntris_target, seed=1):
     spec.objects.append(cornell_walls())
     spec.objects.append((verts, mati))
     return spec
+
+
+# ------------------------------------------------------------------------------------------------
+# MESH-* as files: SURVEY 8(d) specifies the mesh configs "written as OBJ+MTL with Kd/Ks/Ke/Ns/Kn/Kk/Tp
+# and loaded through the build's loader with add_Obj semantics" (main.cpp:552-617).
+def _mtl_block(name, m):
+    kd, ks, ke, N, K, shininess, mtype = m
+    return ("newmtl %s\nKd %r %r %r\nKs %r %r %r\nKe %r %r %r\nNs %r\nKn %r %r %r\nKk %r %r %r\nTp %d\n\n" %
+            ((name,) + tuple(float(x) for x in kd) + tuple(float(x) for x in ks) + tuple(float(x) for x in ke) + (float(shininess),) +
+             tuple(float(x) for x in N) + tuple(float(x) for x in K) + (int(mtype),)))
+
+
+def write_grid_mesh_obj(ntris_target, directory, pos=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0), pitch=0.0, yaw=0.0, name=None, seed=1):
+    """The height field of displaced_grid_mesh() as <name>.obj + <name>.mtl with SHARED vertices, one shape,
+    three `usemtl` bands (WHITE_DIFFUSE, CHROMIUM, GLASS).  The file holds the coordinates add_Obj's
+    transform (negate x, rotate_x(pitch), rotate_y(yaw), * scale + pos: main.cpp:598-606) maps back onto the
+    height field -- up to rounding: what the loader must reproduce bit for bit is ITS OWN arithmetic on the
+    file's numbers, which the tests restate with the oracle.  Returns (obj_path, vertices (nv,3) f32 as
+    written, faces (nt,3) int vertex indices, material index per face relative to the file's materials)."""
+    import os
+    spec = displaced_grid_mesh(ntris_target, seed)
+    verts = spec.objects[1][0].astype(np.float64)                 # (nt, 3, 3) world coordinates
+    nt = verts.shape[0]
+    flat = verts.reshape(-1, 3)
+    uniq, inv = np.unique(flat, axis=0, return_inverse=True)
+    faces = inv.reshape(nt, 3)
+    # inverse of the loader's transform, in double
+    w = (uniq - np.asarray(pos, np.float64)) / np.asarray(scale, np.float64)
+    b = np.float64(np.float32(yaw) / np.float32(180.0) * np.float32(3.141593))
+    g = np.float64(np.float32(pitch) / np.float32(180.0) * np.float32(3.141593))
+    x0 = w[:, 0] * np.cos(b) - w[:, 2] * np.sin(b)                # rotate_y(-yaw)
+    z0 = w[:, 0] * np.sin(b) + w[:, 2] * np.cos(b)
+    y1 = w[:, 1] * np.cos(g) + z0 * np.sin(g)                     # rotate_x(-pitch)
+    z1 = -w[:, 1] * np.sin(g) + z0 * np.cos(g)
+    local = np.stack([-x0, y1, z1], 1).astype(np.float32)
+    name = name or ("mesh_%d" % nt)
+    band_mats = [WHITE_DIFFUSE, CHROMIUM, GLASS]
+    band = (np.arange(nt) * 3) // nt
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, name + ".mtl"), "w") as f:
+        for k, mi in enumerate(band_mats):
+            f.write(_mtl_block("band%d" % k, BUILTIN_MATERIALS[mi]))
+    path = os.path.join(directory, name + ".obj")
+    with open(path, "w") as f:
+        f.write("# displaced grid, %d triangles, %d vertices\nmtllib %s.mtl\no %s\n" % (nt, local.shape[0], name, name))
+        f.write("".join("v %r %r %r\n" % (float(v[0]), float(v[1]), float(v[2])) for v in local))
+        for k in range(3):
+            f.write("usemtl band%d\n" % k)
+            sel = faces[band == k] + 1
+            f.write("".join("f %d %d %d\n" % (a, b_, c) for a, b_, c in sel))
+    return path, local, faces, band.astype(np.uint16)

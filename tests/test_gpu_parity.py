@@ -721,3 +721,125 @@ def test_image_files_of_a_render(api, cb_spec, tmp_path):
     exp8 = np.rint(exp * 255.0).astype(np.uint8)[::-1]
     raw = open(ppm, "rb").read().split(b"\n", 3)
     assert raw[0] == b"P6" and np.array_equal(np.frombuffer(raw[3], dtype=np.uint8).reshape(H, W, 3), exp8)
+
+
+@pytest.mark.parametrize("schedule,k", [(0, -1), (1, 0), (1, 1), (1, 8), (1, 24), (1, 63)])
+def test_schedules_identical(api, oracle, cb_spec, cb_oracle_scene, schedule, k):
+    """The megakernel's two schedules -- 0: lockstep per sample, 1: restart + tail suspension (the wave leaves
+    closest_hit when at most k lanes are still traversing; the stragglers resume in the next trip) -- only
+    change what a wave executes together: same frame, same LCG states, same segment count, on the
+    whole-tree-in-LDS path, the L1/L2 path and the treelet path, with chained passes, with and without the
+    counting kernel instance."""
+    from opencl_path_tracer_amd import scenes
+    W, H = 80, 56
+    fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 8, 5)
+    for lds, count in ((2, 0), (0, 0), (2, 1)):
+        sc = api.Scene(W, H).load(cb_spec)
+        sc.set_option("lds_scene", lds)
+        sc.set_option("schedule", schedule)
+        sc.set_option("suspend_lanes", k)
+        sc.set_option("chunk_spp", 2)
+        sc.set_option("count_work", count)
+        sc.iterations = 8
+        sc.render(5)
+        check(sc, fr, "schedule=%d suspend_lanes=%d lds_scene=%d" % (schedule, k, lds))
+        assert sc.stat("segments") == segs and sc.stat("samples") == W * H * 5
+        if count:
+            assert sc.stat("wave_trips") >= sc.stat("wave_shade_steps") > 0 and sc.stat("node_visits") > sc.stat("wave_node_steps") > 0
+    spec = scenes.displaced_grid_mesh(6000)
+    osc = oracle.load_scene(spec)
+    sc = api.Scene(64, 64).load(spec)
+    sc.set_option("schedule", schedule)
+    sc.set_option("suspend_lanes", k)
+    sc.iterations = 6
+    sc.render(3)
+    fr2, segs2 = oracle_render(oracle, osc, spec, 64, 64, 6, 3)
+    check(sc, fr2, "schedule=%d suspend_lanes=%d treelet" % (schedule, k))
+    assert sc.stat("segments") == segs2
+
+
+def _mesh100k_from_obj(api, oracle, tmp_path, W, H, **ctx_kw):
+    """BASELINE config 3 as SURVEY 8(d) words it: the Cornell walls authored with add_Triangle
+    (main.cpp:793-815) + MESH-100k written as OBJ+MTL (Kd/Ks/Ke/Ns/Kn/Kk/Tp, shared vertices, three usemtl
+    bands) and loaded with pt_add_obj under a non-trivial pos/scale/pitch/yaw.  Returns the product scene,
+    and the vertices / material indices the loader must have authored (the oracle's restatement of
+    main.cpp:598-606 applied to the numbers in the file)."""
+    from opencl_path_tracer_amd import scenes
+    pos, scale, pitch, yaw = (40.0, -15.0, 25.0), (2.0, 2.0, 2.0), 10.0, 30.0
+    path, local, faces, band = scenes.write_grid_mesh_obj(100000, str(tmp_path), pos, scale, pitch, yaw)
+    world = np.array([oracle.obj_vertex(v, pos, scale, pitch, yaw) for v in local], dtype=np.float32)
+    verts = world[faces]
+    mati = (len(scenes.BUILTIN_MATERIALS) + band).astype(np.uint16)        # mat_offset, main.cpp:562
+    sc = api.Scene(W, H, **ctx_kw)
+    for m in scenes.BUILTIN_MATERIALS:
+        sc.add_Material(*m)
+    wv, wm = scenes.cornell_walls()
+    sc.add_Triangles(api.triangles_from_vertices(wv, wm))
+    sc.end_Obj()
+    sc.add_Obj(path, pos, scale, pitch, yaw)
+    sc.upload_Triangles()
+    sc.upload_Materials()
+    sc.set_view(60.0, 0.0, 0.0, (0.0, 0.0, 0.0))
+    return sc, verts, mati
+
+
+def test_config3_mesh_through_add_obj(api, oracle, tmp_path):
+    """Triangles authored by pt_add_obj == the array path fed with the same transformed vertices, bit for
+    bit; materials == the MTL's; the render == the oracle's on those triangles."""
+    from opencl_path_tracer_amd import scenes
+    W, H = 96, 64
+    sc, verts, mati = _mesh100k_from_obj(api, oracle, tmp_path, W, H)
+    tris, mats, objs = sc.debug_scene()
+    assert objs.tolist() == [0, 12] and tris.shape[0] == 12 + verts.shape[0] > 100000
+    assert tris[12:].tobytes() == api.triangles_from_vertices(verts, mati).tobytes()
+    for k, mi in enumerate((scenes.WHITE_DIFFUSE, scenes.CHROMIUM, scenes.GLASS)):
+        assert mats[10 + k].tobytes() == api.Material(*scenes.BUILTIN_MATERIALS[mi])[0].tobytes()
+    assert sc.stat("node_mode") == 2                     # treelet staged in LDS
+    osc = oracle.OracleScene()
+    for m in list(scenes.BUILTIN_MATERIALS) + [scenes.BUILTIN_MATERIALS[i] for i in (scenes.WHITE_DIFFUSE, scenes.CHROMIUM, scenes.GLASS)]:
+        osc.add_Material(*m)
+    wv, wm = scenes.cornell_walls()
+    osc.add_triangles(wv, wm)
+    osc.end_Obj()
+    osc.add_triangles(verts, mati)
+    osc.end_Obj()
+    sc.iterations = 8
+    sc.render(2)
+    cam = oracle.make_camera(60.0, 0.0, 0.0, (0.0, 0.0, 0.0), W, H)
+    fr = oracle.OracleFrame(W, H)
+    segs = fr.render(osc, cam, 8, 0, 2, nthreads=16)
+    check(sc, fr, "config 3 through add_Obj")
+    assert sc.stat("segments") == segs
+
+
+def test_full_size_properties_mesh_1080p(api, oracle, tmp_path):
+    """BASELINE config 3 at full size (OBJ-loaded MESH-100k, 1920x1080, 8 bounces): k samples in one launch
+    == k launches of one == the same under the other schedule / another suspension threshold / with every node through L1/L2; the union of
+    two ranks' tiles == the single-context frame."""
+    W, H, B = 1920, 1080, 8
+    a, _, _ = _mesh100k_from_obj(api, oracle, tmp_path, W, H)
+    a.iterations = B
+    a.render(3)
+    ca, ra = a.read_colors(), a.read_rnds()
+    assert float(ca[:, :3].sum()) > 0
+    del a
+    for opts in ({"steps": 3}, {"schedule": 0}, {"suspend_lanes": 8}, {"lds_scene": 0}):
+        b, _, _ = _mesh100k_from_obj(api, oracle, tmp_path, W, H)
+        steps = opts.pop("steps", 1)
+        for k, v in opts.items():
+            b.set_option(k, v)
+        b.iterations = B
+        for _ in range(steps):
+            b.render(3 // steps)
+        assert same_bits(ca, b.read_colors()) and np.array_equal(ra, b.read_rnds()), str(opts)
+        del b
+    full_c, full_r = np.zeros_like(ca), np.zeros_like(ra)
+    for r in range(2):
+        t, _, _ = _mesh100k_from_obj(api, oracle, tmp_path, W, H, rank=r, world=2, rows_per_block=8)
+        t.iterations = B
+        t.render(3)
+        ids = t.local_pixel_ids()
+        full_c[ids] = t.read_colors()
+        full_r[ids] = t.read_rnds()
+        del t
+    assert same_bits(ca, full_c) and np.array_equal(ra, full_r)

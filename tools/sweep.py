@@ -33,8 +33,9 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
         nv, tt, wn, wt = sc.stat("node_visits"), sc.stat("tri_tests"), sc.stat("wave_node_steps"), sc.stat("wave_tri_steps")
         wsegs = segs / 64.0
         print("   per-tile lane balance (lane segments / 64 x busiest lane): %.1f%%" % (100 * segs / max(sc.stat("tile_lane_steps"), 1)))
-        extra = "  nodes/seg=%.2f tris/seg=%.2f | per wave-segment: node body x%.1f (util %.0f%%), tri body x%.1f (util %.0f%%)" % (
-            nv / segs, tt / segs, wn / wsegs, 100 * nv / (64 * wn), wt / wsegs, 100 * tt / (64 * wt))
+        extra = "  nodes/seg=%.2f tris/seg=%.2f | per wave-segment: node body x%.1f (util %.0f%%), tri body x%.1f (util %.0f%%), shade x%.2f, trips x%.2f, rounds x%.2f" % (
+            nv / segs, tt / segs, wn / wsegs, 100 * nv / (64 * wn), wt / wsegs, 100 * tt / (64 * wt),
+            sc.stat("wave_shade_steps") / wsegs, sc.stat("wave_trips") / wsegs, sc.stat("wave_rounds") / wsegs)
     print("%dx%d b%d spp%d %-34s nodes=%d mode=%d treelet=%d lds_bytes=%6d: %8.1f Msamples/s (kernel %8.1f)  dbar=%.3f  Mseg/s=%.1f%s" % (
         W, H, bounces, spp, str(opts), sc.stat("bvh_nodes"), sc.stat("node_mode"), sc.stat("treelet_nodes"), sc.stat("lds_bytes"), samples / dt / 1e6, samples / kms / 1e3, segs / samples, segs / kms / 1e3, extra), flush=True)
 
