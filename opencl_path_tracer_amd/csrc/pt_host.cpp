@@ -102,7 +102,7 @@ struct pt_context {
     int chunk_spp = -1;   // persistent megakernel work items: > 0 (pass, tile) items of that many samples, 0 whole
                           // tiles, -1 automatic (4 when the context has clearly more tiles than resident waves)
     int sah_visit_cost = 10;   // tenths of a triangle test (option sah_visit_cost)
-    int schedule = 1;      // megakernel: 0 lockstep per sample, 1 restart + tail suspension (default: faster everywhere measured)
+    int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
     int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 24 with the whole tree in LDS, else 48)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
@@ -957,7 +957,11 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
     lc->block = traversal_block(p.node_mode);
     lc->lds_bytes = traversal_lds_bytes(p, lc->block);
     lc->count_work = ctx->count_work != 0;
-    lc->schedule = ctx->schedule;
+    // Restart + tail suspension wins when a wave works through many tiles (one GPU, 1080p: 7.9 per resident wave:
+    // Cornell +2.4 %, mesh scenes +13-18 %); with few tiles per wave the end of a tile -- its slowest pixels finishing
+    // their last samples alone -- is on the critical path and lockstep, whose lanes finish together, wins clearly
+    // (1080p over 4 / 8 ranks: 96 % / 75 % strong-scaling efficiency against 85-90 % / 47-56 %, profiles/r02/e_*).
+    lc->schedule = ctx->schedule >= 0 ? ctx->schedule : (p.n_tiles >= 6 * ctx->cu_count * 16 ? 1 : 0);
     // resident workgroups at 4 waves per SIMD: 4 x 256 threads (nodes through L1/L2), 2 x 512 (whole tree in
     // LDS), 1 x 1024 (treelet) per CU
     lc->persistent_blocks = ctx->cu_count * std::max(1, 1024 / lc->block);
@@ -1285,7 +1289,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "sah_visit_cost: tenths of a triangle test, 0..1000");
         ctx->sah_visit_cost = (int)value;
     } else if (k == "schedule") {
-        if (value < 0 || value > 1) return fail(ctx, PT_EINVAL, "schedule: 0 lockstep per sample, 1 restart + tail suspension");
+        if (value < -1 || value > 1) return fail(ctx, PT_EINVAL, "schedule: -1 automatic, 0 lockstep per sample, 1 restart + tail suspension");
         ctx->schedule = (int)value;
     } else if (k == "suspend_lanes") {
         if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, "suspend_lanes: -1 default, 0..63");

@@ -1,0 +1,150 @@
+"""-m gpu: closed-form radiance cases asserted directly on read_colors() -- NO oracle involved.
+
+The expected values are derived here from prog.cl's text alone, with an independent float64 numpy model of
+the two things they depend on: the per-pixel LCG stream (prog.cl:72-77 + the host seeding main.cpp:522-527,
+exact integer arithmetic) and the pinhole camera (prog.cl:82-92, main.cpp:311-347).  They pin the device code
+against a misreading that the oracle (written by the same hand) could share."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M31 = 2147483647
+EYE_Z = -1299.037842
+LAMP_E = np.array([120.0, 100.0, 80.0])        # main.cpp:753
+SUN_E = np.array([300.0, 250.0, 200.0])        # main.cpp:754
+
+
+def seeds(n):                                   # std::minstd_rand0, default seed, pixel order (main.cpp:45, 522-527)
+    out = np.empty(n, dtype=np.int64)
+    x = 1
+    for i in range(n):
+        x = (x * 16807) % M31
+        out[i] = x
+    return out
+
+
+def draw(state):                                # prog.cl:72-77: returns (new state, float value n / 2^31)
+    state = (state * 48271) % M31
+    return state, state.astype(np.float64) / 2147483648.0
+
+
+def camera_dz(W, H, fov_deg, ids, r1, r2):
+    """z component of the unit camera-ray direction for yaw = pitch = 0 (prog.cl:82-92)."""
+    x = (ids % W) + r1
+    y = (ids // W) + r2
+    ahead = (W / 2.0) / np.tan(np.float32(fov_deg / 2.0 / 180.0 * np.float32(3.141593)).astype(np.float64))
+    dx = (W / 2.0) * (2.0 * x / W - 1.0)
+    dy = (H / 2.0) * (2.0 * y / H - 1.0)
+    return ahead / np.sqrt(dx * dx + dy * dy + ahead * ahead)
+
+
+def quad(z, half=1.0e5):
+    a, b, c, d = (-half, -half, z), (half, -half, z), (half, half, z), (-half, half, z)
+    return np.array([[a, b, c], [a, c, d]], dtype=np.float32)
+
+
+def big_tri(z, L=1.0e7):
+    """One huge triangle around the view axis.  (A +-1e7 quad leaks: a point within ~1 unit of the shared
+    diagonal fails BOTH triangles' inside tests -- the edge function there is below the rounding noise of its
+    2e14-sized terms -- and the view axis (500, 500) lies on that diagonal.  Reference behaviour, reproduced
+    bit for bit by the device; it just is not what this test is about.)"""
+    return np.array([[(-L, -L, z), (3 * L, -L, z), (-L, 3 * L, z)]], dtype=np.float32)
+
+
+def build(api, W, H, fov, objects):
+    from opencl_path_tracer_amd import scenes
+    sc = api.Scene(W, H)
+    for m in scenes.BUILTIN_MATERIALS:
+        sc.add_Material(*m)
+    for verts, mat in objects:
+        sc.add_Triangles(api.triangles_from_vertices(verts, np.full(verts.shape[0], mat, dtype=np.uint16)))
+        sc.end_Obj()
+    sc.upload_Triangles()
+    sc.upload_Materials()
+    sc.set_view(fov, 0.0, 0.0, (0.0, 0.0, 0.0))
+    return sc
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_emitter_seen_in_a_mirror_at_normal_incidence(api, variant):
+    """Camera -> chromium mirror (type 1, prog.cl:341-345) -> emitter behind the camera (type 3,
+    prog.cl:358-366), iterations = 2.  factor_S = Fresnel = F0 + (1 - F0)(1 - |N.D|)^5 = F0 to float precision
+    at (near) normal incidence; the emitter adds emission x (factor_L + factor_B) x factor_S x |D.N| with
+    factor_L = factor_B = 1: every sample is 2 E F0 cos(theta), cos(theta) = the camera ray's z component.
+    Draws per sample: 2 (gen_ray) + 0 (mirror) + 2 (emitter's continuation ray) = 4."""
+    from opencl_path_tracer_amd import scenes
+    W = H = 32
+    S, fov = 24, 2.0
+    sc = build(api, W, H, fov, [(quad(1000.0), scenes.CHROMIUM), (quad(-3000.0), scenes.LAMP)])
+    sc.set_option("variant", variant)
+    sc.iterations = 2
+    sc.render(S)
+    got = sc.read_colors()[:, :3].astype(np.float64)
+    n_, k_ = np.array([3.10, 3.05, 2.05], np.float32), np.array([3.3, 3.3, 2.9], np.float32)     # main.cpp:760
+    F0 = ((k_ * k_ + (n_ - 1) * (n_ - 1)) / (k_ * k_ + (n_ + 1) * (n_ + 1))).astype(np.float64)  # main.cpp:105-109
+    state = seeds(W * H)
+    ids = np.arange(W * H)
+    mean = np.zeros(W * H)
+    for s in range(S):
+        state, r1 = draw(state)
+        state, r2 = draw(state)
+        mean += camera_dz(W, H, fov, ids, r1, r2)
+        state, _ = draw(state)
+        state, _ = draw(state)
+    mean /= S
+    exp = 2.0 * LAMP_E[None, :] * F0[None, :] * mean[:, None]
+    assert np.allclose(got, exp, rtol=2e-5, atol=0), float(np.abs(got / exp - 1).max())
+    assert np.array_equal(sc.read_rnds().astype(np.int64), state)        # exactly 4 draws per sample
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_glass_slab_at_normal_incidence(api, variant):
+    """Camera -> glass slab (two parallel type-2 faces, n = 1.5, prog.cl:228-245, 346-357), iterations = 3.
+    F = F0 = 0.04 on both faces, prob = mean(F) = F0, so the split weights are exactly 1: F / prob = 1 when
+    the path reflects (rnd <= prob), (1 - F) / (1 - prob) = 1 when it refracts.  Per sample:
+      front face reflects            -> SUN emitter behind the camera:  2 E_sun cos,   draws 2 + 1 + 2 + 1
+      front refracts, back refracts  -> LAMP emitter behind the slab:   2 E_lamp cos,  draws 2 + 1 + 1 + 2
+      front refracts, back reflects  -> still inside after 3 segments:  0,             draws 2 + 1 + 1 + 1
+    (cos = the camera ray's z component: mirror reflection and a parallel slab both preserve it; the slab's faces are
+    1e7-sized triangles so that the continuation ray leaving the SUN emitter misses it with probability ~1e-7 per event.)  Which
+    branch a sample takes is decided by the LCG stream, replayed here in exact integer arithmetic."""
+    from opencl_path_tracer_amd import scenes
+    W = H = 32
+    S, fov = 64, 2.0
+    sc = build(api, W, H, fov, [(big_tri(1000.0), scenes.GLASS), (big_tri(1100.0), scenes.GLASS), (quad(2000.0), scenes.LAMP), (quad(-3000.0), scenes.SUN)])
+    sc.set_option("variant", variant)
+    sc.iterations = 3
+    sc.render(S)
+    got = sc.read_colors()[:, :3].astype(np.float64)
+    prob = float(np.float32(0.25) / np.float32(6.25))                    # F0 = ((n-1)/(n+1))^2, main.cpp:105-109
+    thr = prob * 2147483648.0
+    state = seeds(W * H)
+    ids = np.arange(W * H)
+    acc = np.zeros((W * H, 3))
+    n_reflect = n_through = n_trapped = 0
+    safe = np.ones(W * H, bool)
+    for s in range(S):
+        state, r1 = draw(state)
+        state, r2 = draw(state)
+        cz = camera_dz(W, H, fov, ids, r1, r2)
+        state, r3 = draw(state)                                          # front face
+        safe &= np.abs(state - thr) > 64
+        reflect = r3 <= prob
+        s4, r4 = draw(state)                                             # back face (refracted paths) / emitter ray (reflected paths)
+        safe &= reflect | (np.abs(s4 - thr) > 64)
+        through = ~reflect & (r4 > prob)
+        trapped = ~reflect & ~through
+        acc += np.where(reflect[:, None], 2.0 * SUN_E[None, :] * cz[:, None], 0.0) + np.where(through[:, None], 2.0 * LAMP_E[None, :] * cz[:, None], 0.0)
+        s5, _ = draw(s4)
+        s6, _ = draw(s5)
+        state = np.where(trapped, s5, s6)                                # 5 draws when trapped, 6 otherwise
+        n_reflect += int(reflect.sum())
+        n_through += int(through.sum())
+        n_trapped += int(trapped.sum())
+    exp = acc / S
+    assert n_reflect > 1500 and n_trapped > 1500 and n_through > 50000 and safe.sum() > W * H - 4
+    assert abs(n_reflect / (W * H * S) - 0.04) < 0.004                   # the split frequency is Fresnel's
+    ok = safe
+    assert np.allclose(got[ok], exp[ok], rtol=1e-4, atol=1e-3), float(np.abs(got[ok] - exp[ok]).max())
+    assert np.array_equal(sc.read_rnds().astype(np.int64)[ok], state[ok])

@@ -1,5 +1,6 @@
 """Strong-scaling probe on ONE GPU: time the tile set of rank r of an N-rank job (the ranks of a
-real job run concurrently on N GPUs, so the job time is the max over ranks + the exchange)."""
+real job run concurrently on N GPUs, so the job time is the max over ranks + the exchange).
+  python tools/scaling_probe.py [W H] [matrix]"""
 import sys
 import time
 
@@ -8,6 +9,9 @@ from opencl_path_tracer_amd import api, scenes  # noqa: E402
 
 spec = scenes.cornell_box()
 W, H, B, SPP, STEPS = 1920, 1080, 8, 64, 4
+args = [a for a in sys.argv[1:] if a != "matrix"]
+if len(args) >= 2:
+    W, H = int(args[0]), int(args[1])
 
 
 def t_rank(world, rank, rb=8, **opts):
@@ -25,11 +29,15 @@ def t_rank(world, rank, rb=8, **opts):
 
 
 base = t_rank(1, 0)
-print("1 rank : %.3f s  (%.1f Msamples/s)" % (base, W * H * SPP * STEPS / base / 1e6), flush=True)
-b1 = t_rank(1, 0, chunk_spp=4)
-print("1 rank chunk 4: %.3f s  (%.1f Msamples/s)" % (b1, W * H * SPP * STEPS / b1 / 1e6), flush=True)
-for world in (2, 4, 8):
-    for opts in ({}, {"chunk_spp": 4}, {"chunk_spp": 2}):
+print("%dx%d 1 rank : %.4f s  (%.1f Msamples/s)" % (W, H, base, W * H * SPP * STEPS / base / 1e6), flush=True)
+if "matrix" in sys.argv:
+    cases = [dict(schedule=s, **({"suspend_lanes": k} if s else {})) for s, ks in ((0, [0]), (1, [0, 8, 24])) for k in ks]
+    worlds = (4, 8)
+else:
+    cases = [{}]
+    worlds = (2, 4, 8)
+for world in worlds:
+    for opts in cases:
         ts = [t_rank(world, r, **opts) for r in sorted(set([0, world // 2, world - 1]))]
         worst = max(ts)
-        print("%d ranks %-18s: rank times %s -> efficiency %.1f%% vs tile-map N=1 (render only)" % (world, opts, ["%.3f" % x for x in ts], 100 * base / (world * worst)), flush=True)
+        print("%d ranks %-52s: rank times %s -> efficiency %.1f%% vs N=1 (render only)" % (world, opts, ["%.4f" % x for x in ts], 100 * base / (world * worst)), flush=True)
