@@ -170,6 +170,8 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *                  set before the triangles are uploaded
  *   "lds_scene"    2 (default) every workgroup stages BVH nodes in LDS: the whole tree when it fits (<= 64 KB,
  *                  <= 4096 triangles), otherwise its top (the treelet); 0 every node through L1/L2
+ *   "flat_list"    at most this many big triangles (walls, floors: box as large as the box of everything smaller) are
+ *                  kept out of the tree and tested first by every ray (default 16, 0 none); set before the upload
  *   "treelet"      nodes of a large tree to stage: -1 (default) what fits next to one 1,024-thread workgroup's
  *                  stacks (~750-1,000), 0 none, 2..2048; set before the triangles are uploaded
  *   "schedule"     megakernel: 1 a lane whose path ended starts its next sample at once and the wave leaves a traversal
@@ -192,7 +194,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value);
 /* stats: "segments" path segments executed since the last reset, "samples", "kernel_ms" (sum of
  * HIP-event durations of the dominant kernel), "kernel_launches", "bvh_nodes", "bvh_depth",
  * "bvh_build_ms", "bvh_on_device", "triangles", "lds_bytes", "node_mode" (0 whole tree in LDS, 1 L1/L2 only,
- * 2 treelet), "treelet_nodes", and with count_work: "node_visits", "tri_tests", "wave_node_steps",
+ * 2 treelet), "treelet_nodes", "flat_triangles", and with count_work: "node_visits", "tri_tests", "wave_node_steps",
  * "wave_tri_steps", "tile_lane_steps" */
 int pt_get_stat(pt_context* ctx, const char* key, double* out);
 

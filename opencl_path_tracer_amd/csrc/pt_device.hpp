@@ -220,6 +220,8 @@ struct SceneView {
     const float4* tris;        // packets, global memory
     const TriMeta* meta;       // global memory
     unsigned treelet;          // kNodesTreelet: node indices below this are read from lds_nodes
+    int n_flat;                // packets [0, n_flat): big triangles kept out of the tree, tested first (flat_pass)
+    const float4* lds_flat;    // their packets, staged in LDS (broadcast reads instead of a chain of global loads)
 };
 
 // prog.cl:94-112 on one packet; returns t (> 0) or -1.  `limit` is the current closest t: a
@@ -473,12 +475,29 @@ struct Trav {
         const char* tb = reinterpret_cast<const char*>(sv.tris);
         const unsigned off = (unsigned)ti * 48u;
         const float4 a = *reinterpret_cast<const float4*>(tb + off), b = *reinterpret_cast<const float4*>(tb + (off + 16u)), c = *reinterpret_cast<const float4*>(tb + (off + 32u));
+        tri_update<COUNT>(sv, a, b, c, ti, wc);
+    }
+    template <bool COUNT>
+    PT_DEV void tri_update(const SceneView& sv, const float4 a, const float4 b, const float4 c, int ti, WorkCount* wc) {
         if (COUNT) { wc->tris++; if (first_active_lane()) wc->wtris++; }
         const float t = tri_test<MODE == kNodesLds>(a, b, c, P, D, best_t * 1.000002f);
         if (t > 0.0f) {
             bool better = t < best_t;
             if (t == best_t && best >= 0) better = sv.meta[ti].rank < sv.meta[best].rank;
             if (better) { best_t = t; best = ti; }
+        }
+    }
+
+    // The big-triangle list (the host keeps walls, floors ... out of the tree: pt_host.cpp build_and_pack): every
+    // lane tests the same packets in the same order -- a wave-uniform loop at full lane utilisation, the packets
+    // read from their LDS copy (same address on every lane: a broadcast, no chain of global-memory round trips)
+    // -- and what it finds prunes the tree traversal from its first node visit.  Same exact test and tie-break
+    // as in a leaf, so the closest hit is unchanged.
+    template <bool COUNT>
+    PT_DEV void flat_pass(const SceneView& sv, WorkCount* wc) {
+        for (int i = 0; i < sv.n_flat; ++i) {
+            const float4* pk = sv.lds_flat + i * 3;
+            tri_update<COUNT>(sv, pk[0], pk[1], pk[2], i, wc);
         }
     }
 
@@ -529,6 +548,7 @@ template <int MODE, bool COUNT>
 PT_DEV int closest_hit(const SceneView& sv, f3 P, f3 D, const LaneStack<typename StackOf<MODE>::type> stk, float* t_out, WorkCount* wc) {
     Trav<MODE> tr;
     tr.begin(P, D, stk);
+    tr.template flat_pass<COUNT>(sv, wc);
     while (!tr.done()) tr.template round<COUNT>(sv, wc);
     *t_out = tr.best_t;
     return tr.best;
@@ -695,14 +715,18 @@ PT_DEV void stage_nodes(const RenderParams& p, float4* lds_nodes) {
     }
 }
 
-// LDS layout of every traversal kernel: [per-lane stacks: stack_entries x BLOCK entries][staged nodes]
+// LDS layout of every traversal kernel: [per-lane stacks: stack_entries x BLOCK entries][staged nodes][flat packets]
 template <int MODE, int BLOCK>
 PT_DEV size_t traversal_stack_bytes_dev(const RenderParams& p) {
     return ((size_t)p.stack_entries * sizeof(typename StackOf<MODE>::type) * BLOCK + 15) & ~(size_t)15;
 }
 template <int MODE, int BLOCK>
-PT_DEV size_t traversal_lds_bytes_dev(const RenderParams& p) {      // == traversal_lds_bytes() on the host
+PT_DEV size_t traversal_nodes_end_dev(const RenderParams& p) {
     return traversal_stack_bytes_dev<MODE, BLOCK>(p) + (MODE == kNodesLds ? (size_t)p.n_nodes * 64 : MODE == kNodesTreelet ? (size_t)p.treelet_nodes * 64 : 0);
+}
+template <int MODE, int BLOCK>
+PT_DEV size_t traversal_lds_bytes_dev(const RenderParams& p) {      // == traversal_lds_bytes() on the host
+    return traversal_nodes_end_dev<MODE, BLOCK>(p) + (size_t)p.n_flat * 48;
 }
 template <int MODE, int BLOCK>
 PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<typename StackOf<MODE>::type>* stk) {
@@ -713,13 +737,17 @@ PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<type
     sv->tris = p.tris;
     sv->meta = p.meta;
     sv->treelet = (unsigned)p.treelet_nodes;
+    sv->n_flat = p.n_flat;
     sv->lds_nodes = nullptr;
+    float4* lds_flat = reinterpret_cast<float4*>(pt_lds_raw + traversal_nodes_end_dev<MODE, BLOCK>(p));
+    for (int i = threadIdx.x; i < p.n_flat * 3; i += BLOCK) lds_flat[i] = p.tris[i];
+    sv->lds_flat = lds_flat;
     if (MODE != kNodesGlobal) {
         float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + traversal_stack_bytes_dev<MODE, BLOCK>(p));
         stage_nodes<MODE>(p, lds_nodes);
-        __syncthreads();
         sv->lds_nodes = lds_nodes;
     }
+    __syncthreads();
 }
 
 // statistics live in kStatRows rows of 8 counters; a block adds to the row picked by its index, so

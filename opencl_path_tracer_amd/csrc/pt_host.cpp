@@ -64,6 +64,7 @@ struct pt_context {
     std::vector<TriMeta> meta;
     std::vector<int32_t> orig;
     int bvh_depth = 0;
+    int n_flat = 0;             // packed triangles [0, n_flat): the big-triangle list tested before the tree
 
     // ---- device buffers
     float4* d_nodes = nullptr;
@@ -102,6 +103,7 @@ struct pt_context {
     int chunk_spp = -1;   // persistent megakernel work items: > 0 (pass, tile) items of that many samples, 0 whole
                           // tiles, -1 automatic (4 when the context has clearly more tiles than resident waves)
     int sah_visit_cost = 10;   // tenths of a triangle test (option sah_visit_cost)
+    int flat_list = 16;        // at most this many big triangles go to the flat list (option flat_list; 0: none)
     int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
     int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 24 with the whole tree in LDS, else 48)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
@@ -361,14 +363,15 @@ Aabb padded_bounds(const pt_triangle& t) {
 // One build attempt.  Returns PT_OK and fills bld.
 void compute_cost_boxes_impl(pt_context* ctx);
 
-int build_attempt(pt_context* ctx, BvhBuilder& bld, const std::vector<BuildPrim>& prims, int max_leaf, bool force_leaf) {
+int build_attempt(pt_context* ctx, BvhBuilder& bld, const std::vector<BuildPrim>& prims, const std::vector<int32_t>& flat, int max_leaf, bool force_leaf) {
     bld = BvhBuilder();
     bld.prims = prims;
     bld.max_leaf = max_leaf;
     bld.force_leaf = force_leaf;
     bld.visit_cost = (float)ctx->sah_visit_cost * 0.1f;
     bld.nodes.reserve(prims.size());
-    bld.order.reserve(prims.size());
+    bld.order.reserve(prims.size() + flat.size());
+    bld.order = flat;            // the flat list comes first in packed order; leaf ranges start behind it
     // The root must be an interior node: wrap a leaf / an empty scene.
     Aabb lb, rb;
     lb.reset();
@@ -408,10 +411,45 @@ int build_and_pack(pt_context* ctx) {
         p.tri = (int32_t)i;
         prims.push_back(p);
     }
+    // Big-triangle list: a triangle whose box is as large as the box of everything smaller than it (walls, a
+    // floor) sits near the root of any BVH, widens the boxes of the nodes above it, and every ray pays a
+    // node-phase / leaf-phase alternation to reach it.  Up to `flat_list` such triangles are kept OUT of the tree
+    // and tested first, by every lane, in a wave-uniform loop (full lane utilisation, scalar packet loads); their
+    // hits then prune the traversal of the rest from its first visit.  Candidates in order of box area: the m
+    // biggest qualify when each is >= 1/16 of the area of the box around all the other triangles (largest such m).
+    std::vector<int32_t> flat;
+    if (ctx->flat_list > 0 && !prims.empty()) {
+        std::vector<size_t> by_area(prims.size());
+        std::iota(by_area.begin(), by_area.end(), (size_t)0);
+        std::stable_sort(by_area.begin(), by_area.end(), [&](size_t a, size_t b) { return prims[a].box.half_area() > prims[b].box.half_area(); });
+        const size_t cand = std::min<size_t>((size_t)ctx->flat_list, prims.size());
+        std::vector<Aabb> rest(cand + 1);             // rest[k] = box of by_area[k..]
+        Aabb tail;
+        tail.reset();
+        for (size_t k = prims.size(); k-- > cand;) tail.grow(prims[by_area[k]].box);
+        rest[cand] = tail;
+        for (size_t k = cand; k-- > 0;) { tail.grow(prims[by_area[k]].box); rest[k] = tail; }
+        // the largest m such that each of the m biggest is >= 1/16 of the box around all the others
+        std::vector<char> is_flat(prims.size(), 0);
+        for (size_t m = cand; m > 0; --m) {
+            const float smallest = prims[by_area[m - 1]].box.half_area(), others = rest[m].half_area();
+            if (smallest >= others * (1.0f / 16.0f)) {
+                for (size_t k = 0; k < m; ++k) is_flat[by_area[k]] = 1;
+                break;
+            }
+        }
+        std::vector<BuildPrim> kept;
+        kept.reserve(prims.size());
+        for (size_t i = 0; i < prims.size(); ++i) {
+            if (is_flat[i]) flat.push_back(prims[i].tri); else kept.push_back(prims[i]);      // add order within the list
+        }
+        prims.swap(kept);
+    }
     BvhBuilder bld;
-    int rc = ctx->bvh_policy <= 1 ? build_attempt(ctx, bld, prims, 4, false)
-                                  : build_attempt(ctx, bld, prims, ctx->bvh_policy == 2 ? 4 : 8, true);
+    int rc = ctx->bvh_policy <= 1 ? build_attempt(ctx, bld, prims, flat, 4, false)
+                                  : build_attempt(ctx, bld, prims, flat, ctx->bvh_policy == 2 ? 4 : 8, true);
     if (rc != PT_OK) return rc;
+    ctx->n_flat = (int)flat.size();
     if (bld.max_depth_seen > kMaxDepth) return fail(ctx, PT_ESCENE, "internal: BVH deeper than the traversal stack");
     ctx->bvh_depth = bld.max_depth_seen;
     ctx->nodes.swap(bld.nodes);
@@ -473,7 +511,7 @@ constexpr size_t kLdsSlack = 8 * 1024;     // wf_intersect's compaction arrays l
 // Does the whole tree fit next to two 512-thread workgroups per CU (kNodesLds: 16-bit references)?
 bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int bvh_depth) {
     const bool s16 = n_nodes <= 32767 && n_tris <= 4096;
-    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(bvh_depth) * 2 * 512 + 32 <= kLdsPerCu / 2;
+    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(bvh_depth) * 2 * 512 + 64 * sizeof(TriPacket) + 32 <= kLdsPerCu / 2;   // (+ flat list)
 }
 
 // Treelet: when the tree is too large for LDS, the T nodes with the largest boxes --
@@ -570,6 +608,7 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->rows_per_block = ctx->rows_per_block;
     p->n_nodes = (int32_t)ctx->nodes.size();
     p->n_tris = (int32_t)ctx->orig.size();
+    p->n_flat = ctx->n_flat;
     p->stack_entries = stack_entries_for(ctx->bvh_depth);
     // where the traversal reads nodes from: the whole tree staged in LDS, its re-indexed top, or L1/L2 only
     p->node_mode = kNodesGlobal;
@@ -876,6 +915,7 @@ static int build_on_device(pt_context* ctx, bool* done) {
     PT_HIP(ctx, hipMemcpy(ctx->orig.data(), r.d_orig, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(r.d_orig);
     ctx->bvh_depth = r.depth + 1;
+    ctx->n_flat = 0;              // the device builder puts every triangle in the tree
     plan_node_placement(ctx);
     if (ctx->treelet_nodes > 0) PT_HIP(ctx, hipMemcpy(ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size(), hipMemcpyHostToDevice));
     *done = true;
@@ -1291,6 +1331,10 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "schedule") {
         if (value < -1 || value > 1) return fail(ctx, PT_EINVAL, "schedule: -1 automatic, 0 lockstep per sample, 1 restart + tail suspension");
         ctx->schedule = (int)value;
+    } else if (k == "flat_list") {
+        if (value < 0 || value > 64) return fail(ctx, PT_EINVAL, "flat_list: 0..64 big triangles tested before the tree");
+        ctx->flat_list = (int)value;
+        ctx->tris_uploaded = false;
     } else if (k == "suspend_lanes") {
         if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, "suspend_lanes: -1 default, 0..63");
         ctx->suspend_lanes = (int)value;
@@ -1329,6 +1373,7 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out) {
     if (k == "triangles") { *out = (double)ctx->orig.size(); return PT_OK; }
     if (k == "lds_bytes") { *out = (double)ctx->last_lds_bytes; return PT_OK; }
     if (k == "treelet_nodes") { *out = (double)ctx->treelet_nodes; return PT_OK; }
+    if (k == "flat_triangles") { *out = (double)ctx->n_flat; return PT_OK; }
     if (k == "node_mode") {      // what the next launch will use: 0 whole tree in LDS, 1 L1/L2 only, 2 treelet
         pt_camera cam;
         std::memset(&cam, 0, sizeof cam);

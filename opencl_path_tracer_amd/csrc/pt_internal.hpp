@@ -68,6 +68,7 @@ struct RenderParams {
     int32_t rank, world, rows_per_block;
     int32_t iterations, first_sample, nsamples;
     int32_t n_nodes, n_tris;
+    int32_t n_flat;              // packets [0, n_flat) are the big-triangle list: tested by every ray before the tree
     int32_t node_mode;           // kNodesLds / kNodesGlobal / kNodesTreelet: where the traversal reads BVH nodes from
     int32_t treelet_nodes;       // kNodesTreelet: nodes [0, treelet_nodes) are staged in LDS
     int32_t stack_entries;       // per-lane stack depth actually needed (sentinel + BVH depth + the slot above the top)

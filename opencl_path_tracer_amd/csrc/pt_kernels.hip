@@ -155,7 +155,10 @@ PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, con
         bool finished = true;
         if (traversing || bounce < p.iterations) {
             tr.setup(rP, rD);                  // direction-dependent constants: recomputed for new and resumed rays alike
-            if (!traversing) tr.restart(stk);
+            if (!traversing) {
+                tr.restart(stk);
+                tr.template flat_pass<COUNT>(sv, wc);
+            }
             for (;;) {
                 if (COUNT && first_active_lane()) wc->wrounds++;
                 tr.template round<COUNT>(sv, wc);
@@ -356,7 +359,7 @@ size_t traversal_lds_bytes(const RenderParams& p, int block) {
     b = (b + 15) & ~(size_t)15;
     if (p.node_mode == kNodesLds) b += (size_t)p.n_nodes * 64;
     if (p.node_mode == kNodesTreelet) b += (size_t)p.treelet_nodes * 64;
-    return b;
+    return b + (size_t)p.n_flat * 48;          // the big-triangle list's packets
 }
 
 hipError_t launch_gen_ray(const RenderParams& p, hipStream_t stream) {

@@ -159,18 +159,35 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
         const unsigned cend = min(cbase + (unsigned)kWfRaysPerWave, n);
         if (cbase > cend) cbase = cend;
         Trav<MODE> tr;
+        // the big-triangle list first, for the wave's whole range with every lane busy: the hit record of a ray
+        // starts out as its closest hit among them (the flat loop below would run this per refilled lane)
+        if (sv.n_flat > 0) {
+            for (unsigned r = cbase + (threadIdx.x & 63); r < cend; r += 64) {
+                const float4 A = rsA[r];
+                const float2 Bq = *reinterpret_cast<const float2*>(&rsB[r]);
+                tr.begin(mk(A.x, A.y, A.z), mk(A.w, Bq.x, Bq.y), stk);
+                tr.template flat_pass<false>(sv, &wc);
+                hits[r] = make_float2(tr.best_t, __int_as_float(tr.best));
+            }
+            __threadfence_block();       // the records are read back by other lanes of this wave
+        }
         tr.begin(mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), stk);
         tr.idle();
         unsigned pos = ~0u;          // stream position of the ray in flight (~0u: none)
         unsigned npos = ~0u;         // prefetched next ray (~0u: none)
         float4 nA = make_float4(0.f, 0.f, 0.f, 0.f);
         float2 nB = make_float2(0.f, 1.f);
+        float2 nH = make_float2(0.f, 0.f);
         for (;;) {
             // ---- lanes whose ray is finished switch to their prefetched ray
             if (tr.done() && npos != ~0u) {
                 pos = npos;
                 npos = ~0u;
                 tr.begin(mk(nA.x, nA.y, nA.z), mk(nA.w, nB.x, nB.y), stk);
+                if (sv.n_flat > 0) {
+                    tr.best_t = nH.x;
+                    tr.best = __float_as_int(nH.y);
+                }
             }
             // ---- lanes without a prefetched ray reserve the next positions of the wave's range
             const unsigned long long want = __ballot(npos == ~0u);
@@ -180,6 +197,7 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
                     npos = my;
                     nA = rsA[my];
                     nB = *reinterpret_cast<const float2*>(&rsB[my]);
+                    if (sv.n_flat > 0) nH = hits[my];
                 }
                 cbase = min(cbase + (unsigned)__popcll(want), cend);
             }

@@ -52,9 +52,11 @@ def leaves_reaching(nodes, P, D):
     return out
 
 
-def validate_structure(nodes, tris, ntris):
-    """Every packed triangle is in exactly one leaf and inside that leaf's box."""
+def validate_structure(nodes, tris, ntris, n_flat=0):
+    """Every packed triangle behind the flat list [0, n_flat) is in exactly one leaf and inside that leaf's
+    box; the flat list is in no leaf."""
     seen = np.zeros(ntris, dtype=int)
+    seen[:n_flat] = 1
     depth_max = 0
     stack = [(0, 0)]
     while stack:
@@ -74,7 +76,8 @@ def validate_structure(nodes, tris, ntris):
             v = ~ref
             first, count = v >> 3, (v & 7) + 1
             for k in range(first, first + count):
-                seen[k] += 1
+                assert k >= n_flat or ntris == n_flat, "a flat-list triangle is referenced by a leaf"
+                seen[k] += k >= n_flat
                 pts = tris[k, :9].reshape(3, 3)
                 assert np.all(pts >= lo - 0) and np.all(pts <= hi + 0), "triangle %d outside its leaf box" % k
     assert (seen == 1).all()

@@ -617,7 +617,7 @@ def test_device_bvh_builder(api, oracle, cb_spec, cb_oracle_scene, which, ntris)
     nodes, tris, meta, orig = sc.debug_bvh()
     assert sorted(orig.tolist()) == list(range(spec.ntris))
     if spec.ntris < 10000:
-        depth = bvh_check.validate_structure(nodes, tris, spec.ntris)
+        depth = bvh_check.validate_structure(nodes, tris, spec.ntris, int(sc.stat("flat_triangles")))
         assert depth <= sc.stat("bvh_depth")
     sc.iterations = 6
     sc.render(2)

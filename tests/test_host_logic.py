@@ -37,7 +37,9 @@ def test_bvh_structure(api, cb_spec):
     sc = api.Scene(16, 16, device=None).load(cb_spec)
     nodes, tris, meta, orig = sc.debug_bvh()
     assert tris.shape[0] == 1932 and sorted(orig.tolist()) == list(range(1932))
-    depth = bvh_check.validate_structure(nodes, tris, 1932)
+    assert sc.stat("flat_triangles") == 12          # the walls and the lamp: tested before the tree, in add order
+    assert orig[:12].tolist() == list(range(12))
+    depth = bvh_check.validate_structure(nodes, tris, 1932, 12)
     assert depth <= sc.stat("bvh_depth") <= 30
     # packets hold exactly the twelve floats prog.cl:94-112 reads, in add order via `orig`
     verts = np.concatenate([v for v, _ in cb_spec.objects]).reshape(-1, 9)
@@ -61,7 +63,8 @@ def test_treelet_reindexing(api, ntris, want):
     nodes, tris, meta, orig = sc.debug_bvh()
     T = int(sc.stat("treelet_nodes"))
     assert sorted(orig.tolist()) == list(range(spec.ntris))
-    bvh_check.validate_structure(nodes, tris, spec.ntris)
+    assert sc.stat("flat_triangles") == 12
+    bvh_check.validate_structure(nodes, tris, spec.ntris, 12)
     if want == 0:
         assert T == 0 and sc.stat("node_mode") == 1
         return
@@ -90,6 +93,27 @@ def test_treelet_reindexing(api, ntris, want):
         assert area[frontier].max() <= area[:T].min()
 
 
+def test_flat_list_selection(api, cb_spec):
+    """The big-triangle list: the m biggest triangles, each >= 1/16 of the box around all the others.  Cornell
+    box: the 10 wall / floor / ceiling triangles AND the 2 lamp triangles (the lamp is small, but not against
+    the spheres' box); option flat_list caps it; a uniform mesh alone has none."""
+    from opencl_path_tracer_amd import scenes
+    import copy
+    for cap, want in ((16, 12), (12, 12), (10, 10), (4, 4), (0, 0)):
+        sc = api.Scene(16, 16, device=None)
+        sc.set_option("flat_list", cap)
+        sc.load(cb_spec)
+        nodes, tris, meta, orig = sc.debug_bvh()
+        assert sc.stat("flat_triangles") == want and sorted(orig.tolist()) == list(range(1932))
+        bvh_check.validate_structure(nodes, tris, 1932, want)
+        if want == 10:
+            assert orig[:10].tolist() == list(range(2, 12))        # the lamp (triangles 0, 1) is the smallest of the twelve
+    mesh_only = copy.deepcopy(scenes.displaced_grid_mesh(6000))
+    mesh_only.objects = mesh_only.objects[1:]
+    sc = api.Scene(16, 16, device=None).load(mesh_only)
+    assert sc.stat("flat_triangles") == 0
+
+
 def test_scene_size_cap(api):
     """Device offsets are 32-bit (packet index * 48, node index << 6): pt_add_triangles refuses more than
     2^26 triangles before it reads anything."""
@@ -105,7 +129,7 @@ def test_scene_size_cap(api):
 def test_option_validation(api):
     sc = api.Scene(8, 8, device=None)
     for key, bad in (("variant", 2), ("lds_scene", 1), ("lds_scene", 3), ("treelet", -2), ("treelet", 5000), ("chunk_spp", -2),
-                     ("sah_visit_cost", -1), ("schedule", 2), ("schedule", -2), ("tile_order", 1), ("suspend_lanes", 64), ("suspend_lanes", -2), ("debug_repeat", -1), ("debug_repeat", 100000), ("bvh_policy", 5),
+                     ("sah_visit_cost", -1), ("schedule", 2), ("schedule", -2), ("flat_list", -1), ("flat_list", 65), ("tile_order", 1), ("suspend_lanes", 64), ("suspend_lanes", -2), ("debug_repeat", -1), ("debug_repeat", 100000), ("bvh_policy", 5),
                      ("block", 256), ("min_waves", 4), ("traversal", 1), ("pixel_map", 1), ("no_such_option", 0)):
         with pytest.raises(api.PtError) as e:
             sc.set_option(key, bad)
@@ -114,9 +138,10 @@ def test_option_validation(api):
 
 def test_bvh_never_culls_a_real_hit(api, oracle, cb_spec, cb_oracle_scene):
     """For random rays, the triangle the oracle's exhaustive search (mode 2) returns must lie in a
-    leaf that the ray's box chain reaches in the product BVH."""
+    leaf that the ray's box chain reaches in the product BVH (or in the big-triangle list in front of it)."""
     sc = api.Scene(16, 16, device=None).load(cb_spec)
     nodes, tris, meta, orig = sc.debug_bvh()
+    n_flat = int(sc.stat("flat_triangles"))
     rng = np.random.RandomState(3)
     n = 300
     rays = np.zeros(n, dtype=oracle.RAY)
@@ -134,7 +159,7 @@ def test_bvh_never_culls_a_real_hit(api, oracle, cb_spec, cb_oracle_scene):
         if not hits[i]["t"] > 0:
             continue
         Pd, Dd = rays[i]["P"][:3].astype(np.float64), rays[i]["D"][:3].astype(np.float64)
-        reach = bvh_check.leaves_reaching(nodes, Pd, Dd)
+        reach = bvh_check.leaves_reaching(nodes, Pd, Dd) + [(0, n_flat)]      # the flat list is tested by every ray
         best_t, found = float(hits[i]["t"]), False
         for first, count in reach:
             for k in range(first, first + count):
@@ -158,7 +183,7 @@ def test_tiny_and_empty_scenes_build(api):
     sc.upload_Triangles()
     nodes, tris, meta, orig = sc.debug_bvh()
     assert nodes.shape[0] == 1 and tris.shape[0] == 1
-    assert bvh_check.validate_structure(nodes, tris, 1) == 0
+    assert sc.stat("flat_triangles") == 1 and bvh_check.validate_structure(nodes, tris, 1, 1) == 0
 
 
 @pytest.mark.parametrize("H,world,rb", [(64, 1, 8), (64, 2, 8), (1080, 8, 8), (37, 4, 8), (100, 3, 16), (5, 8, 8)])

@@ -22,7 +22,7 @@ def load():
     rays, alive = ws.get_rays(spec)
     W, H, B = ws.W, ws.H, ws.B
     ph, nr, t = ws.traces(spec, rays.reshape(-1, 8), 0)
-    return ph.reshape(B, W * H, ws.MAXR, 2), nr.reshape(B, W * H), alive
+    return ph.reshape(B, W * H, ws.MAXR, 3)[..., :2], nr.reshape(B, W * H), alive
 
 
 def sim(ph, nr, alive, K, M, S=8, ntiles=150, seed=5):

@@ -26,7 +26,7 @@ static float tri_test(const Tri* T, const float P[3], const float D[3]) {
     return t;
 }
 
-// rays: n x 8 floats (P.xyz pad D.xyz pad).  phases: n x max_rounds x 2 uint16 (node visits, tri tests per round),
+// rays: n x 8 floats (P.xyz pad D.xyz pad).  phases: n x max_rounds x 3 uint16 (node visits, tri tests, leaves per round),
 // nrounds: n.  defer = the global path's postponed-leaf variant.
 void trav_trace(const Node64* nodes, const Tri* tris, const float* rays, int64_t n, int max_rounds, int defer,
                 uint16_t* phases, int32_t* nrounds, float* out_t) {
@@ -36,10 +36,10 @@ void trav_trace(const Node64* nodes, const Tri* tris, const float* rays, int64_t
         float best = INFINITY;
         int32_t stack[64]; int sp = 0; stack[0] = 0x7fffffff;
         int32_t cur = 0, pend = 0; int r = 0;
-        uint16_t* ph = phases + (size_t)i * max_rounds * 2;
-        memset(ph, 0, sizeof(uint16_t) * 2 * max_rounds);
+        uint16_t* ph = phases + (size_t)i * max_rounds * 3;
+        memset(ph, 0, sizeof(uint16_t) * 3 * max_rounds);
         while (cur != 0x7fffffff && r < max_rounds) {
-            int nn = 0, nt = 0;
+            int nn = 0, nt = 0, nl = 0;
             while (cur >= 0 && cur != 0x7fffffff) {
                 const Node64* nd = &nodes[cur];
                 ++nn;
@@ -70,15 +70,17 @@ void trav_trace(const Node64* nodes, const Tri* tris, const float* rays, int64_t
             }
             if (defer && pend != 0) {
                 int v = ~pend, first = v >> 3, count = (v & 7) + 1;
+                ++nl;
                 for (int j = 0; j < count; ++j) { float t = tri_test(&tris[first+j], P, D); ++nt; if (t > 0 && t < best) best = t; }
                 pend = 0;
             }
             while (cur < 0) {
                 int v = ~cur, first = v >> 3, count = (v & 7) + 1;
+                ++nl;
                 for (int j = 0; j < count; ++j) { float t = tri_test(&tris[first+j], P, D); ++nt; if (t > 0 && t < best) best = t; }
                 cur = stack[sp]; --sp;
             }
-            ph[2*r] = (uint16_t)nn; ph[2*r+1] = (uint16_t)nt; ++r;
+            ph[3*r] = (uint16_t)nn; ph[3*r+1] = (uint16_t)nt; ph[3*r+2] = (uint16_t)nl; ++r;
         }
         nrounds[i] = r;
         out_t[i] = best;

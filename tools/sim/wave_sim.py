@@ -45,14 +45,16 @@ def get_rays(spec):
     return rays, alive
 
 
-def traces(spec, rays, defer=0):
+def traces(spec, rays, defer=0, bvh_spec=None):
+    """bvh_spec: trace the rays against the BVH of ANOTHER scene (e.g. the spheres without the walls)."""
+    spec = bvh_spec or spec
     sc = api.Scene(16, 16, device=None)
     sc.set_option("treelet", 0)
     sc.load(spec)
     nodes, tris, meta, orig = sc.debug_bvh()
     L = C.CDLL(os.path.join(HERE, "libtravtrace.so"))
     n = rays.shape[0]
-    ph = np.zeros((n, MAXR, 2), np.uint16)
+    ph = np.zeros((n, MAXR, 3), np.uint16)
     nr = np.zeros(n, np.int32)
     t = np.zeros(n, np.float32)
     rays = np.ascontiguousarray(rays)
@@ -89,7 +91,7 @@ def replay(ph, nr, idx):
         # per lane: concatenated phase list of its k rays
         seqs = [np.concatenate([ph[i, :nr[i]] for i in idx[w, l]]) for l in range(lanes)]
         R = max(len(s) for s in seqs)
-        M = np.zeros((lanes, R, 2), np.int64)
+        M = np.zeros((lanes, R, 3), np.int64)
         for l, s in enumerate(seqs):
             M[l, :len(s)] = s
         wn += M[:, :, 0].max(0).sum()
