@@ -178,7 +178,7 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *                  when at most "suspend_lanes" lanes are unfinished (they resume in the next trip); 0 lockstep: all
  *                  lanes of a wave start a sample together; -1 (default) 1 when the context has >= 6 tiles per
  *                  resident wave (one or two GPUs at 1080p), else 0
- *   "suspend_lanes" -1 (default: 24 with the whole tree in LDS, otherwise 48), 0..63
+ *   "suspend_lanes" -1 (default: 16 with the whole tree in LDS, otherwise 24), 0..63
  *   "persistent"   1 (default) megakernel grid only fills the chip and every wave pulls its next 8x8
  *                  tile from a global counter; 0 one workgroup per group of tiles
  *   "chunk_spp"    persistent megakernel work items: n > 0 (pass, tile) items of n samples, chained per tile

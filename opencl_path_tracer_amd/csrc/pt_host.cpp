@@ -105,7 +105,7 @@ struct pt_context {
     int sah_visit_cost = 10;   // tenths of a triangle test (option sah_visit_cost)
     int flat_list = 16;        // at most this many big triangles go to the flat list (option flat_list; 0: none)
     int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
-    int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 24 with the whole tree in LDS, else 48)
+    int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 16 with the whole tree in LDS, else 24)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
     int bvh_policy = 0;   // 0/1 host SAH with SAH leaf termination, 2 leaves of <= 4, 3 leaves of <= 8, 4 device LBVH
@@ -625,9 +625,9 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->chunk_spp = 0;
     p->tile_done = nullptr;
     p->n_tiles = ((ctx->W + 7) / 8) * ((ctx->local_rows + 7) / 8);
-    // measured (profiles/r02/d_*): Cornell box in LDS 16 / 24 / 32 -> 1515 / 1532 / 1526 Msamples/s (lockstep 1495);
-    // MESH-100k 32 / 40 / 48 / 56 -> 569 / 580 / 580 / 580 (lockstep 511); MESH-1M 205 at 48 (lockstep 173)
-    p->suspend_lanes = ctx->suspend_lanes >= 0 ? ctx->suspend_lanes : (p->node_mode == kNodesLds ? 24 : 48);
+    // measured with the big-triangle list in place (profiles/r02/i_*): Cornell box in LDS 8 / 16 / 24 / 32 -> 1669 / 1690 /
+    // 1680 / 1669 Msamples/s (lockstep 1671); MESH-100k 24 / 32 / 48 -> 600 / 599 / 595 (lockstep 571); MESH-1M 211 / 210 / 205 (191)
+    p->suspend_lanes = ctx->suspend_lanes >= 0 ? ctx->suspend_lanes : (p->node_mode == kNodesLds ? 16 : 24);
 }
 
 int check_ready(pt_context* ctx, const pt_camera* cam) {

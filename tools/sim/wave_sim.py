@@ -50,6 +50,7 @@ def traces(spec, rays, defer=0, bvh_spec=None):
     spec = bvh_spec or spec
     sc = api.Scene(16, 16, device=None)
     sc.set_option("treelet", 0)
+    sc.set_option("flat_list", 0)        # the traces describe ONE tree over everything it is given
     sc.load(spec)
     nodes, tris, meta, orig = sc.debug_bvh()
     L = C.CDLL(os.path.join(HERE, "libtravtrace.so"))
