@@ -639,12 +639,16 @@ PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, c
         if (type == 0) {
             const float idiff = max0(dot3(nr.D, N));
             fL = fL * (ldf3(m->kd) * idiff);
-            const f3 view = normalize3(ldf3(p.cam.eye) - hp);
-            const f3 halfway = normalize3(view + nr.D);
-            const float ispec = max0(dot3(N, halfway));
-            // m->_pad = 1: ks is exactly 0 and shininess is finite >= 0, so ks * pow(...) is +0 whatever the
-            // (finite) power is -- skip the double-precision pow (set by pt_upload_materials)
-            const float pw = m->_pad ? 1.0f : spec_pow(ispec, m->shininess);
+            // m->_pad = 1: ks is exactly 0 and shininess is finite >= 0, so ks * pow(...) is +-0 whatever the
+            // (finite) power is -- skip the halfway vector (two normalisations) and the double-precision pow
+            // (set by pt_upload_materials)
+            float pw = 1.0f;
+            if (!m->_pad) {
+                const f3 view = normalize3(ldf3(p.cam.eye) - hp);
+                const f3 halfway = normalize3(view + nr.D);
+                const float ispec = max0(dot3(N, halfway));
+                pw = spec_pow(ispec, m->shininess);
+            }
             fB = fB * (ldf3(m->ks) * pw);
         } else {
             const f3 e = ((ldf3(m->emission) * (fL + fB)) * fS) * fR;
