@@ -395,34 +395,19 @@ int build_attempt(pt_context* ctx, BvhBuilder& bld, const std::vector<BuildPrim>
     return PT_OK;
 }
 
-int build_and_pack(pt_context* ctx) {
-    const size_t n = ctx->tris.size();
-    std::vector<BuildPrim> prims;
-    prims.reserve(n);
-    for (size_t i = 0; i < n; ++i) {
-        const pt_triangle& t = ctx->tris[i];
-        bool finite = true;
-        for (int a = 0; a < 3; ++a)
-            finite = finite && std::isfinite(t.r1.s[a]) && std::isfinite(t.r2.s[a]) && std::isfinite(t.r3.s[a]);
-        if (!finite) continue;  // cannot be hit (prog.cl:99-106 compares NaN) and has no box
-        BuildPrim p;
-        p.box = padded_bounds(t);
-        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.box.lo[a] + p.box.hi[a]);
-        p.tri = (int32_t)i;
-        prims.push_back(p);
-    }
-    // Big-triangle list: a triangle whose box is as large as the box of everything smaller than it (walls, a
-    // floor) sits near the root of any BVH, widens the boxes of the nodes above it, and every ray pays a
-    // node-phase / leaf-phase alternation to reach it.  Up to `flat_list` such triangles are kept OUT of the tree
-    // and tested first, by every lane, in a wave-uniform loop (full lane utilisation, scalar packet loads); their
-    // hits then prune the traversal of the rest from its first visit.  Candidates in order of box area: the m
-    // biggest qualify when each is >= 1/16 of the area of the box around all the other triangles (largest such m).
+// The big-triangle list: removes the chosen primitives from `prims` and returns their
+// add-order triangle indices (in add order).
+std::vector<int32_t> select_flat_list(const pt_context* ctx, std::vector<BuildPrim>& prims) {
     std::vector<int32_t> flat;
     if (ctx->flat_list > 0 && !prims.empty()) {
+        // only the `cand` biggest need to be in order (ties: add order), the others only need their common box
+        std::vector<float> area(prims.size());
+        for (size_t i = 0; i < prims.size(); ++i) area[i] = prims[i].box.half_area();
         std::vector<size_t> by_area(prims.size());
         std::iota(by_area.begin(), by_area.end(), (size_t)0);
-        std::stable_sort(by_area.begin(), by_area.end(), [&](size_t a, size_t b) { return prims[a].box.half_area() > prims[b].box.half_area(); });
         const size_t cand = std::min<size_t>((size_t)ctx->flat_list, prims.size());
+        std::partial_sort(by_area.begin(), by_area.begin() + (std::ptrdiff_t)cand, by_area.end(),
+                          [&](size_t a, size_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); });
         std::vector<Aabb> rest(cand + 1);             // rest[k] = box of by_area[k..]
         Aabb tail;
         tail.reset();
@@ -445,6 +430,32 @@ int build_and_pack(pt_context* ctx) {
         }
         prims.swap(kept);
     }
+    return flat;
+}
+
+int build_and_pack(pt_context* ctx) {
+    const size_t n = ctx->tris.size();
+    std::vector<BuildPrim> prims;
+    prims.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const pt_triangle& t = ctx->tris[i];
+        bool finite = true;
+        for (int a = 0; a < 3; ++a)
+            finite = finite && std::isfinite(t.r1.s[a]) && std::isfinite(t.r2.s[a]) && std::isfinite(t.r3.s[a]);
+        if (!finite) continue;  // cannot be hit (prog.cl:99-106 compares NaN) and has no box
+        BuildPrim p;
+        p.box = padded_bounds(t);
+        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.box.lo[a] + p.box.hi[a]);
+        p.tri = (int32_t)i;
+        prims.push_back(p);
+    }
+    // Big-triangle list: a triangle whose box is as large as the box of everything smaller than it (walls, a
+    // floor) sits near the root of any BVH, widens the boxes of the nodes above it, and every ray pays a
+    // node-phase / leaf-phase alternation to reach it.  Up to `flat_list` such triangles are kept OUT of the tree
+    // and tested first, by every lane, in a wave-uniform loop (full lane utilisation, scalar packet loads); their
+    // hits then prune the traversal of the rest from its first visit.  Candidates in order of box area: the m
+    // biggest qualify when each is >= 1/16 of the area of the box around all the other triangles (largest such m).
+    std::vector<int32_t> flat = select_flat_list(ctx, prims);
     BvhBuilder bld;
     int rc = ctx->bvh_policy <= 1 ? build_attempt(ctx, bld, prims, flat, 4, false)
                                   : build_attempt(ctx, bld, prims, flat, ctx->bvh_policy == 2 ? 4 : 8, true);
@@ -893,31 +904,79 @@ static int build_on_device(pt_context* ctx, bool* done) {
         for (int a = 0; a < 3; ++a)
             if (!std::isfinite(t.r1.s[a]) || !std::isfinite(t.r2.s[a]) || !std::isfinite(t.r3.s[a])) return PT_OK;   // host path handles those
     PT_HIP(ctx, hipSetDevice(ctx->device));
+    // the big-triangle list is chosen on the host (one pass over the boxes); the device builds the tree of the rest
+    std::vector<BuildPrim> prims((size_t)n);
+    for (int i = 0; i < n; ++i) { prims[(size_t)i].box = padded_bounds(ctx->tris[(size_t)i]); prims[(size_t)i].tri = i; }
+    const std::vector<int32_t> flat = select_flat_list(ctx, prims);
+    const int nf = (int)flat.size(), ns = n - nf;
+    if (ns <= 2 * kMaxLeaf) return PT_OK;
+    std::vector<pt_triangle> sub_tris;
+    std::vector<int32_t> sub_rank, sub_orig;
+    const pt_triangle* b_tris = ctx->tris.data();
+    const int32_t* b_rank = ctx->enc_rank.data();
+    if (nf > 0) {
+        sub_tris.reserve((size_t)ns);
+        sub_rank.reserve((size_t)ns);
+        sub_orig.reserve((size_t)ns);
+        for (const BuildPrim& bp : prims) { sub_tris.push_back(ctx->tris[(size_t)bp.tri]); sub_rank.push_back(ctx->enc_rank[(size_t)bp.tri]); sub_orig.push_back(bp.tri); }
+        b_tris = sub_tris.data();
+        b_rank = sub_rank.data();
+    }
     LbvhResult r;
-    PT_HIP(ctx, lbvh_build(ctx->tris.data(), ctx->enc_rank.data(), n, ctx->stream, &r));
+    PT_HIP(ctx, lbvh_build(b_tris, b_rank, ns, ctx->stream, &r));
+    auto drop = [&]() { (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta); (void)hipFree(r.d_orig); };
     if (r.depth + 5 > kStackEntries) {          // deeper than the traversal stack: let the host builder do it
-        (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta); (void)hipFree(r.d_orig);
+        drop();
         return PT_OK;
     }
-    if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
-    if (ctx->d_tris) (void)hipFree(ctx->d_tris);
-    if (ctx->d_meta) (void)hipFree(ctx->d_meta);
-    ctx->d_nodes = r.d_nodes;
-    ctx->d_tris = r.d_tris;
-    ctx->d_meta = r.d_meta;
     ctx->nodes.resize((size_t)r.n_nodes);
     ctx->packets.resize((size_t)n);
     ctx->meta.resize((size_t)n);
     ctx->orig.resize((size_t)n);
-    PT_HIP(ctx, hipMemcpy(ctx->nodes.data(), r.d_nodes, sizeof(Node64) * (size_t)r.n_nodes, hipMemcpyDeviceToHost));
-    PT_HIP(ctx, hipMemcpy(ctx->packets.data(), r.d_tris, sizeof(TriPacket) * (size_t)n, hipMemcpyDeviceToHost));
-    PT_HIP(ctx, hipMemcpy(ctx->meta.data(), r.d_meta, sizeof(TriMeta) * (size_t)n, hipMemcpyDeviceToHost));
-    PT_HIP(ctx, hipMemcpy(ctx->orig.data(), r.d_orig, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    hipError_t e = hipMemcpy(ctx->nodes.data(), r.d_nodes, sizeof(Node64) * (size_t)r.n_nodes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ctx->packets.data() + nf, r.d_tris, sizeof(TriPacket) * (size_t)ns, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ctx->meta.data() + nf, r.d_meta, sizeof(TriMeta) * (size_t)ns, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ctx->orig.data() + nf, r.d_orig, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { drop(); return fail(ctx, PT_EHIP, std::string("device BVH download: ") + hipGetErrorString(e)); }
     (void)hipFree(r.d_orig);
+    r.d_orig = nullptr;
     ctx->bvh_depth = r.depth + 1;
-    ctx->n_flat = 0;              // the device builder puts every triangle in the tree
+    ctx->n_flat = nf;
+    if (nf > 0) {
+        // the list's packets go in front; leaf ranges move up by nf (a leaf reference is ~(first << 3 | count - 1))
+        for (int k = 0; k < nf; ++k) {
+            const pt_triangle& t = ctx->tris[(size_t)flat[(size_t)k]];
+            float* v = ctx->packets[(size_t)k].v;
+            v[0] = t.r1.s[0]; v[1] = t.r1.s[1]; v[2] = t.r1.s[2];
+            v[3] = t.r2.s[0]; v[4] = t.r2.s[1]; v[5] = t.r2.s[2];
+            v[6] = t.r3.s[0]; v[7] = t.r3.s[1]; v[8] = t.r3.s[2];
+            v[9] = t.N.s[0]; v[10] = t.N.s[1]; v[11] = t.N.s[2];
+            ctx->meta[(size_t)k].rank = ctx->enc_rank[(size_t)flat[(size_t)k]];
+            ctx->meta[(size_t)k].mati = t.mati;
+            ctx->orig[(size_t)k] = flat[(size_t)k];
+        }
+        for (int k = nf; k < n; ++k) ctx->orig[(size_t)k] = sub_orig[(size_t)ctx->orig[(size_t)k]];
+        for (Node64& nd : ctx->nodes) {
+            if (nd.left < 0) nd.left -= nf << 3;
+            if (nd.right < 0) nd.right -= nf << 3;
+        }
+    }
     plan_node_placement(ctx);
-    if (ctx->treelet_nodes > 0) PT_HIP(ctx, hipMemcpy(ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size(), hipMemcpyHostToDevice));
+    int rc = PT_OK;
+    if (nf > 0) {                 // recomposed on the host: replace the builder's device arrays
+        (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta);
+        if ((rc = upload_vec(ctx, &ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size())) != PT_OK) return rc;
+        if ((rc = upload_vec(ctx, &ctx->d_tris, ctx->packets.data(), sizeof(TriPacket) * ctx->packets.size())) != PT_OK) return rc;
+        if ((rc = upload_vec(ctx, &ctx->d_meta, ctx->meta.data(), sizeof(TriMeta) * ctx->meta.size())) != PT_OK) return rc;
+    } else {
+        if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
+        if (ctx->d_tris) (void)hipFree(ctx->d_tris);
+        if (ctx->d_meta) (void)hipFree(ctx->d_meta);
+        ctx->d_nodes = r.d_nodes;
+        ctx->d_tris = r.d_tris;
+        ctx->d_meta = r.d_meta;
+        if (ctx->treelet_nodes > 0) PT_HIP(ctx, hipMemcpy(ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size(), hipMemcpyHostToDevice));
+    }
     *done = true;
     return PT_OK;
 }

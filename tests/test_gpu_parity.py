@@ -843,3 +843,41 @@ def test_full_size_properties_mesh_1080p(api, oracle, tmp_path):
         full_r[ids] = t.read_rnds()
         del t
     assert same_bits(ca, full_c) and np.array_equal(ra, full_r)
+
+
+def test_cabi_exchange_next_to_torch_rccl(api, cb_spec):
+    """The situation of `bench.py --gpus N`: torch.distributed has initialised ITS RCCL communicator (backend
+    nccl) in this process, and the library then binds librccl at run time (sharing the copy torch loaded),
+    creates its own communicator from an id carried by torch, and gathers on torch's current stream.  One rank
+    here (N > 1 needs N GPUs); run in a child process so that the process group does not outlive the test."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from opencl_path_tracer_amd import api, scenes
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+t = torch.ones(4, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
+sc = api.Scene(64, 40, device=0, rank=0, world=1, rows_per_block=8).load(scenes.cornell_box())
+slab = torch.zeros((sc.slab_pixels, 4), dtype=torch.float32, device="cuda")
+rnds = torch.zeros((sc.slab_pixels,), dtype=torch.int32, device="cuda")
+sc.bind_framebuffer(slab.data_ptr(), rnds.data_ptr())
+sc.set_stream(torch.cuda.current_stream().cuda_stream)
+box = [api.comm_unique_id()]
+dist.broadcast_object_list(box, src=0)
+sc.comm_init(box[0])
+sc.iterations = 4
+sc.render(2)
+sc.gather_frame()
+torch.cuda.synchronize()
+frame = sc.read_frame()
+assert np.array_equal(frame.view(np.uint32), slab.cpu().numpy().view(np.uint32)) and float(frame[:, :3].sum()) > 0
+dist.destroy_process_group()
+print("EXCHANGE_OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "EXCHANGE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
