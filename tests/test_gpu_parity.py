@@ -881,3 +881,17 @@ print("EXCHANGE_OK")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "EXCHANGE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_work_item_counter_range_is_checked(api, cb_spec):
+    """Work items of one persistent launch are numbered with 31 bits on the device (passes x tiles): a call that
+    would overflow them is refused up front instead of indexing out of range."""
+    sc = api.Scene(1920, 1080).load(cb_spec)
+    sc.set_option("chunk_spp", 1)
+    sc.iterations = 1
+    with pytest.raises(api.PtError) as e:
+        sc.render(70000)                    # 70,000 passes x 32,400 tiles > 2^31
+    assert e.value.code == api.PT_EINVAL and "work-item" in str(e.value)
+    assert sc.current_sample == 0
+    sc.render(2)                            # the context is still usable
+    assert sc.current_sample == 2

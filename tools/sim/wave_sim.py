@@ -22,7 +22,7 @@ MAXR = 48
 
 
 def get_rays(spec):
-    cache = "/tmp/wave_sim_rays_%s.npz" % spec.name
+    cache = "/tmp/wave_sim_rays_%s_%dx%d.npz" % (spec.name, W, H)
     if os.path.exists(cache):
         z = np.load(cache)
         return z["rays"], z["alive"]
