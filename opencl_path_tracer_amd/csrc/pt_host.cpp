@@ -1165,11 +1165,13 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         p.tile_counter = ctx->d_tile_counter;
         // automatic: chaining passes only pays when there are enough tiles to re-balance; with about one
         // tile per resident wave (a 1080p frame over 8 GPUs) the most expensive tile is the critical path
-        // either way and the extra hand-offs cost 2-4 %.  With many tiles per wave (one GPU, 1080p: 7.9)
-        // passes of 8 samples re-balance just as well as passes of 4 and halve the hand-overs
-        // (measured 0 / 2 / 4 / 8 / 16 -> 1409 / 1406 / 1456 / 1470 / 1465 Msamples/s).
+        // either way and the extra hand-offs cost 2-4 %.  With many tiles per wave (one GPU, 1080p: 7.9) the
+        // launch runs the suspend schedule, whose items end with their slowest pixels finishing alone: long
+        // passes amortise that tail, and half a launch's samples still re-balance the chip -- 64 spp per launch:
+        // 8 / 16 / 32 / 64 -> 1689 / 1760 / 1787 / 1761 Msamples/s; 256 spp: 1706 / 1789 / 1843 / 1868
+        // (profiles/r02/n_*; the lockstep kernel of round 1 peaked at 8).
         const int resident_waves = ctx->cu_count * 16;
-        const int auto_chunk = p.n_tiles >= 6 * resident_waves ? 8 : (p.n_tiles > resident_waves + resident_waves / 2 ? 4 : 0);
+        const int auto_chunk = p.n_tiles >= 6 * resident_waves ? (nsamples >= 256 ? 64 : 32) : (p.n_tiles > resident_waves + resident_waves / 2 ? 4 : 0);
         const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk;
         // work items are numbered with an int on the device: passes x tiles + one failed fetch per resident wave
         const int64_t items = chunk > 0 ? ((int64_t)nsamples + chunk - 1) / chunk * p.n_tiles : p.n_tiles;
