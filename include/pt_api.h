@@ -171,7 +171,7 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *   "lds_scene"    2 (default) every workgroup stages BVH nodes in LDS: the whole tree when it fits (<= 64 KB,
  *                  <= 4096 triangles), otherwise its top (the treelet); 0 every node through L1/L2
  *   "flat_list"    at most this many big triangles (walls, floors: box as large as the box of everything smaller) are
- *                  kept out of the tree and tested first by every ray (default 16, 0 none); set before the upload
+ *                  kept out of the tree and tested first by every ray (default 16, 0 none, at most 32); set before the upload
  *   "treelet"      nodes of a large tree to stage: -1 (default) what fits next to one 1,024-thread workgroup's
  *                  stacks (~750-1,000), 0 none, 2..2048; set before the triangles are uploaded
  *   "schedule"     megakernel: 1 a lane whose path ended starts its next sample at once and the wave leaves a traversal

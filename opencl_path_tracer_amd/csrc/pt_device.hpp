@@ -221,7 +221,8 @@ struct SceneView {
     const TriMeta* meta;       // global memory
     unsigned treelet;          // kNodesTreelet: node indices below this are read from lds_nodes
     int n_flat;                // packets [0, n_flat): big triangles kept out of the tree, tested first (flat_pass)
-    const float4* lds_flat;    // their packets, staged in LDS (broadcast reads instead of a chain of global loads)
+    const float4* lds_flat;    // their packets, staged in LDS
+    const char* lds_fbox;      // their padded boxes, 48 B each: per axis {lo, hi, hi, lo} (planes picked by address, like a staged node)
 };
 
 // prog.cl:94-112 on one packet; returns t (> 0) or -1.  `limit` is the current closest t: a
@@ -488,14 +489,35 @@ struct Trav {
         }
     }
 
-    // The big-triangle list (the host keeps walls, floors ... out of the tree: pt_host.cpp build_and_pack): every
-    // lane tests the same packets in the same order -- a wave-uniform loop at full lane utilisation, the packets
-    // read from their LDS copy (same address on every lane: a broadcast, no chain of global-memory round trips)
-    // -- and what it finds prunes the tree traversal from its first node visit.  Same exact test and tie-break
-    // as in a leaf, so the closest hit is unchanged.
+    // The big-triangle list (the host keeps walls, floors ... out of the tree: pt_host.cpp build_and_pack), tested
+    // at the start of every traversal; what it finds prunes the tree from its first node visit.  Two passes:
+    //  1. every lane slab-tests the padded box of every listed triangle -- a wave-uniform loop at full lane
+    //     utilisation, 14 VALU + 3 broadcast-free LDS reads per box, planes picked by address from the direction
+    //     signs exactly as for a staged node -- and notes the boxes it touches in a bit mask (the same conservative
+    //     cull a leaf box performs in the tree);
+    //  2. each lane runs the exact test only on ITS candidates (2-6 of the 12 in the Cornell box: a wall is two
+    //     triangles with one box, and a ray may cross the planes of a few walls), packets read from the LDS copy
+    //     at a per-lane address.
+    // Same exact test and tie-break as in a leaf, so the closest hit is unchanged.  (Testing all 12 exactly on
+    // every lane cost 984 VALU per pass, a third of the kernel's instructions; this form ~600.)
     template <bool COUNT>
     PT_DEV void flat_pass(const SceneView& sv, WorkCount* wc) {
+        const float kWiden = 1.0000005f;
+        unsigned mask = 0;
+#pragma clang loop unroll(disable) vectorize(disable)      // (unrolled x8 it spills 40 registers around the loop)
         for (int i = 0; i < sv.n_flat; ++i) {
+            const char* bb = sv.lds_fbox + i * 48;
+            const float2 x = *reinterpret_cast<const float2*>(bb + onx);      // (entry plane, exit plane) of the axis
+            const float2 y = *reinterpret_cast<const float2*>(bb + ony);
+            const float2 z = *reinterpret_cast<const float2*>(bb + onz);
+            const float tn = fmaxf(fmaxf(fmaf_(x.x, inv.x, cn.x), fmaf_(y.x, inv.y, cn.y)), fmaf_(z.x, inv.z, cn.z));
+            const float tf = fminf(fminf(fmaf_(x.y, inv.x, cf.x), fmaf_(y.y, inv.y, cf.y)), fmaf_(z.y, inv.z, cf.z)) * kWiden;
+            mask |= ((tf >= tn) && (tf >= 0.0f)) ? (1u << i) : 0u;
+        }
+#pragma clang loop unroll(disable)
+        while (mask != 0) {
+            const int i = __ffs((int)mask) - 1;
+            mask &= mask - 1;
             const float4* pk = sv.lds_flat + i * 3;
             tri_update<COUNT>(sv, pk[0], pk[1], pk[2], i, wc);
         }
@@ -730,7 +752,7 @@ PT_DEV size_t traversal_nodes_end_dev(const RenderParams& p) {
 }
 template <int MODE, int BLOCK>
 PT_DEV size_t traversal_lds_bytes_dev(const RenderParams& p) {      // == traversal_lds_bytes() on the host
-    return traversal_nodes_end_dev<MODE, BLOCK>(p) + (size_t)p.n_flat * 48;
+    return traversal_nodes_end_dev<MODE, BLOCK>(p) + (size_t)p.n_flat * 96;     // packets + boxes of the big-triangle list
 }
 template <int MODE, int BLOCK>
 PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<typename StackOf<MODE>::type>* stk) {
@@ -746,6 +768,23 @@ PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<type
     float4* lds_flat = reinterpret_cast<float4*>(pt_lds_raw + traversal_nodes_end_dev<MODE, BLOCK>(p));
     for (int i = threadIdx.x; i < p.n_flat * 3; i += BLOCK) lds_flat[i] = p.tris[i];
     sv->lds_flat = lds_flat;
+    // padded boxes of the listed triangles (what padded_bounds() gives a triangle in a leaf: 1e-5 of the largest
+    // coordinate + 1e-6), per axis {lo, hi, hi, lo} so that (entry, exit) is one 8-byte read at + 0 or + 8
+    float* lds_fbox = reinterpret_cast<float*>(lds_flat + p.n_flat * 3);
+    for (int i = threadIdx.x; i < p.n_flat; i += BLOCK) {
+        const float4 a = p.tris[i * 3], b = p.tris[i * 3 + 1], c = p.tris[i * 3 + 2];
+        const float lox = fminf(fminf(a.x, a.w), b.z), hix = fmaxf(fmaxf(a.x, a.w), b.z);
+        const float loy = fminf(fminf(a.y, b.x), b.w), hiy = fmaxf(fmaxf(a.y, b.x), b.w);
+        const float loz = fminf(fminf(a.z, b.y), c.x), hiz = fmaxf(fmaxf(a.z, b.y), c.x);
+        const float mx = fmaxf(__builtin_fabsf(lox), __builtin_fabsf(hix)), my = fmaxf(__builtin_fabsf(loy), __builtin_fabsf(hiy));
+        const float mz = fmaxf(__builtin_fabsf(loz), __builtin_fabsf(hiz));
+        const float pad = fmaxf(fmaxf(mx, my), mz) * 1e-5f + 1e-6f;
+        float4* rec = reinterpret_cast<float4*>(lds_fbox + i * 12);
+        rec[0] = make_float4(lox - pad, hix + pad, hix + pad, lox - pad);
+        rec[1] = make_float4(loy - pad, hiy + pad, hiy + pad, loy - pad);
+        rec[2] = make_float4(loz - pad, hiz + pad, hiz + pad, loz - pad);
+    }
+    sv->lds_fbox = reinterpret_cast<const char*>(lds_fbox);
     if (MODE != kNodesGlobal) {
         float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + traversal_stack_bytes_dev<MODE, BLOCK>(p));
         stage_nodes<MODE>(p, lds_nodes);

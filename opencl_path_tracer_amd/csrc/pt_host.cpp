@@ -522,7 +522,7 @@ constexpr size_t kLdsSlack = 8 * 1024;     // wf_intersect's compaction arrays l
 // Does the whole tree fit next to two 512-thread workgroups per CU (kNodesLds: 16-bit references)?
 bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int bvh_depth) {
     const bool s16 = n_nodes <= 32767 && n_tris <= 4096;
-    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(bvh_depth) * 2 * 512 + 64 * sizeof(TriPacket) + 32 <= kLdsPerCu / 2;   // (+ flat list)
+    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(bvh_depth) * 2 * 512 + 32 * 96 + 32 <= kLdsPerCu / 2;   // (+ flat list: packet + box per triangle)
 }
 
 // Treelet: when the tree is too large for LDS, the T nodes with the largest boxes --
@@ -1393,7 +1393,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < -1 || value > 1) return fail(ctx, PT_EINVAL, "schedule: -1 automatic, 0 lockstep per sample, 1 restart + tail suspension");
         ctx->schedule = (int)value;
     } else if (k == "flat_list") {
-        if (value < 0 || value > 64) return fail(ctx, PT_EINVAL, "flat_list: 0..64 big triangles tested before the tree");
+        if (value < 0 || value > 32) return fail(ctx, PT_EINVAL, "flat_list: 0..32 big triangles tested before the tree (a 32-bit candidate mask per lane)");
         ctx->flat_list = (int)value;
         ctx->tris_uploaded = false;
     } else if (k == "suspend_lanes") {
