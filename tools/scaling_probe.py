@@ -31,8 +31,8 @@ def t_rank(world, rank, rb=8, **opts):
 base = t_rank(1, 0)
 print("%dx%d 1 rank : %.4f s  (%.1f Msamples/s)" % (W, H, base, W * H * SPP * STEPS / base / 1e6), flush=True)
 if "matrix" in sys.argv:
-    cases = [dict(schedule=s, **({"suspend_lanes": k} if s else {})) for s, ks in ((0, [0]), (1, [0, 8, 24])) for k in ks]
-    worlds = (4, 8)
+    cases = [dict(schedule=0), dict(schedule=1), dict(schedule=1, chunk_spp=0), dict(schedule=1, chunk_spp=16), dict(schedule=0, chunk_spp=0), dict(schedule=0, chunk_spp=8)]
+    worlds = (2, 4, 8)
 else:
     cases = [{}]
     worlds = (2, 4, 8)
