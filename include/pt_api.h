@@ -176,7 +176,7 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *                  stacks (~750-1,000), 0 none, 2..2048; set before the triangles are uploaded
  *   "schedule"     megakernel: 1 a lane whose path ended starts its next sample at once and the wave leaves a traversal
  *                  when at most "suspend_lanes" lanes are unfinished (they resume in the next trip); 0 lockstep: all
- *                  lanes of a wave start a sample together; -1 (default) 1 when the context has >= 6 tiles per
+ *                  lanes of a wave start a sample together; -1 (default) 1 when the context has >= 3 tiles per
  *                  resident wave (one or two GPUs at 1080p), else 0
  *   "suspend_lanes" -1 (default: 16 with the whole tree in LDS, otherwise 24), 0..63
  *   "persistent"   1 (default) megakernel grid only fills the chip and every wave pulls its next 8x8

@@ -1059,8 +1059,9 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
     // Restart + tail suspension wins when a wave works through many tiles (one GPU, 1080p: 7.9 per resident wave:
     // Cornell +2.4 %, mesh scenes +13-18 %); with few tiles per wave the end of a tile -- its slowest pixels finishing
     // their last samples alone -- is on the critical path and lockstep, whose lanes finish together, wins clearly
-    // (1080p over 4 / 8 ranks: 96 % / 75 % strong-scaling efficiency against 85-90 % / 47-56 %, profiles/r02/e_*).
-    lc->schedule = ctx->schedule >= 0 ? ctx->schedule : (p.n_tiles >= 6 * ctx->cu_count * 16 ? 1 : 0);
+    // (1080p over 4 / 8 ranks: 87 % / 62 % strong-scaling efficiency against 73 % / 42 %; over 2 ranks suspend wins again:
+    // 95.7 % against 88 %; profiles/r02/e_*, q_*).
+    lc->schedule = ctx->schedule >= 0 ? ctx->schedule : (p.n_tiles >= 3 * ctx->cu_count * 16 ? 1 : 0);
     // resident workgroups at 4 waves per SIMD: 4 x 256 threads (nodes through L1/L2), 2 x 512 (whole tree in
     // LDS), 1 x 1024 (treelet) per CU
     lc->persistent_blocks = ctx->cu_count * std::max(1, 1024 / lc->block);
@@ -1171,7 +1172,11 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         // 8 / 16 / 32 / 64 -> 1689 / 1760 / 1787 / 1761 Msamples/s; 256 spp: 1706 / 1789 / 1843 / 1868
         // (profiles/r02/n_*; the lockstep kernel of round 1 peaked at 8).
         const int resident_waves = ctx->cu_count * 16;
-        const int auto_chunk = p.n_tiles >= 6 * resident_waves ? (nsamples >= 256 ? 64 : 32) : (p.n_tiles > resident_waves + resident_waves / 2 ? 4 : 0);
+        // fewer tiles per resident wave (1080p over 2 / 4 / 8 GPUs: 4.0 / 2.0 / 1.0): suspend with passes of 16, lockstep with
+        // passes of 8, lockstep with whole tiles (profiles/r02/q_*: 95.7 % / 87.5 % / 61.8 % of the one-GPU rate per GPU)
+        const int auto_chunk = p.n_tiles >= 6 * resident_waves ? (nsamples >= 256 ? 64 : 32)
+                             : p.n_tiles >= 3 * resident_waves ? 16
+                             : p.n_tiles > resident_waves + resident_waves / 2 ? 8 : 0;
         const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk;
         // work items are numbered with an int on the device: passes x tiles + one failed fetch per resident wave
         const int64_t items = chunk > 0 ? ((int64_t)nsamples + chunk - 1) / chunk * p.n_tiles : p.n_tiles;
