@@ -517,7 +517,9 @@ void compute_cost_boxes_impl(pt_context* ctx) {
 int stack_entries_for(int bvh_depth) { return std::min(kStackEntries, ((bvh_depth + 4) + 1) & ~1); }
 
 constexpr size_t kLdsPerCu = 160 * 1024;
-constexpr size_t kLdsSlack = 8 * 1024;     // wf_intersect's compaction arrays live next to the stacks and nodes
+// next to the stacks and the staged nodes: the big-triangle list (96 B each) and, in wf_intersect, one class byte per ray
+// of a trip (16 waves x 256) + the compaction counters
+constexpr size_t kLdsSlack = 32 * 96 + 4096 + 1024 + 256;
 
 // Does the whole tree fit next to two 512-thread workgroups per CU (kNodesLds: 16-bit references)?
 bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int bvh_depth) {

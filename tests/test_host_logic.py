@@ -71,7 +71,7 @@ def test_treelet_reindexing(api, ntris, want):
     assert sc.stat("node_mode") == 2
     depth = int(sc.stat("bvh_depth"))
     entries = min(36, ((depth + 4) + 1) & ~1)
-    cap = (160 * 1024 - 8 * 1024 - entries * 4 * 1024) // 64
+    cap = (160 * 1024 - (32 * 96 + 4096 + 1024 + 256) - entries * 4 * 1024) // 64      # kLdsSlack: flat list + wf_intersect's arrays
     assert T == min(cap if want < 0 else min(cap, want), nodes.shape[0]) and T >= 2
     left, right = nodes[:, 12].view(np.int32), nodes[:, 13].view(np.int32)
     parent = np.full(nodes.shape[0], -1)
