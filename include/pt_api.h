@@ -169,11 +169,10 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *   "bvh_policy"   0 host SAH (default), 2 / 3 host SAH with leaves forced to <= 4 / <= 8 triangles, 4 device LBVH;
  *                  set before the triangles are uploaded
  *   "lds_scene"    2 (default) every workgroup stages BVH nodes in LDS: the whole tree when it fits (<= 64 KB,
- *                  <= 4096 triangles), otherwise its top (the treelet); 0 every node through L1/L2
- *   "flat_list"    at most this many big triangles (walls, floors: box as large as the box of everything smaller) are
- *                  kept out of the tree and tested first by every ray (default 16, 0 none, at most 32); set before the upload
- *   "treelet"      nodes of a large tree to stage: -1 (default) what fits next to one 1,024-thread workgroup's
- *                  stacks (~750-1,000), 0 none, 2..2048; set before the triangles are uploaded
+ *                  <= 4096 triangles), otherwise its top if "treelet" asks for one; 0 every node through L1/L2
+ *   "treelet"      nodes of a LARGE tree to stage in LDS (the ones with the biggest boxes, renumbered to the front):
+ *                  0 (default) none -- with the big-triangle list in place it no longer pays --, -1 what fits next to
+ *                  one 1,024-thread workgroup's stacks (~750-1,000), 2..2048; set before the triangles are uploaded
  *   "schedule"     megakernel: 1 a lane whose path ended starts its next sample at once and the wave leaves a traversal
  *                  when at most "suspend_lanes" lanes are unfinished (they resume in the next trip); 0 lockstep: all
  *                  lanes of a wave start a sample together; -1 (default) 1 when the context has >= 3 tiles per

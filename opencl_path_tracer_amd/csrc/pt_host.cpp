@@ -90,7 +90,8 @@ struct pt_context {
     int variant = 0;
     int lds_scene = 2;   // 2: stage BVH nodes in LDS -- the whole tree when it fits next to two 512-thread blocks per
                          // CU, otherwise its top (`treelet`); 0: every node through L1/L2
-    int treelet = -1;    // nodes of a large tree to stage in LDS: -1 what fits one 1,024-thread block per CU, 0 none, n
+    int treelet = 0;     // nodes of a large tree to stage in LDS: 0 none (default: with the big-triangle list in place the
+                         // treelet no longer pays, profiles/r02/s_*), -1 what fits one 1,024-thread block per CU, n
     int treelet_nodes = 0;   // decided at upload: nodes [0, treelet_nodes) are the re-indexed top of the tree
     int timing = 0;
     int count_work = 0;
@@ -1381,7 +1382,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value != 0 && value != 2) return fail(ctx, PT_EINVAL, "lds_scene: 0 every node through L1/L2, 2 stage the tree (or its top) in LDS");
         ctx->lds_scene = (int)value;
     } else if (k == "treelet") {
-        if (value < -1 || value > 2048) return fail(ctx, PT_EINVAL, "treelet: -1 automatic, 0 off, 2..2048 nodes");
+        if (value < -1 || value > 2048) return fail(ctx, PT_EINVAL, "treelet: 0 off, -1 as many nodes as fit, 2..2048 nodes");
         ctx->treelet = (int)value;
         ctx->tris_uploaded = false;                  // the tree is re-indexed at upload
     } else if (k == "timing") {

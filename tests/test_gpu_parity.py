@@ -178,7 +178,7 @@ def test_tiled_ranks_union_equals_single(api, oracle, cb_spec, cb_oracle_scene):
 
 
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("lds,treelet", [(2, -1), (2, 40), (0, -1)])
+@pytest.mark.parametrize("lds,treelet", [(2, -1), (2, 40), (0, -1), (2, 0)])
 def test_mesh_scene_treelet_and_global_paths(api, oracle, lds, treelet, variant):
     """A scene too large for whole-tree staging (displaced grid, ~6k triangles, ~3k nodes, all four
     material types reachable): the top of the tree is staged in LDS (treelet: automatic size, or only 40
@@ -193,7 +193,7 @@ def test_mesh_scene_treelet_and_global_paths(api, oracle, lds, treelet, variant)
     sc.set_option("lds_scene", lds)
     sc.set_option("variant", variant)
     sc.load(spec)
-    assert sc.stat("node_mode") == (2 if lds else 1)
+    assert sc.stat("node_mode") == (2 if lds and treelet else 1)
     if lds and treelet == 40:
         assert sc.stat("treelet_nodes") == 40
     sc.iterations = 6
@@ -431,10 +431,11 @@ def test_mesh_configs_c3_c5(api, oracle, ntris, W, H, bounces, spp, variant, lds
     from opencl_path_tracer_amd import scenes
     spec = scenes.displaced_grid_mesh(ntris)
     osc = oracle.load_scene(spec)
-    sc = api.Scene(W, H).load(spec)
+    sc = api.Scene(W, H)
+    sc.set_option("treelet", -1 if lds else 0)     # lds 2: the top of the tree staged in LDS; 0 (the default): L1/L2 only
+    sc.load(spec)
     sc.set_option("variant", variant)
-    sc.set_option("lds_scene", lds)               # 2: treelet staged in LDS (default), 0: L1/L2 only
-    assert sc.stat("node_mode") == (2 if lds else 1) and sc.stat("treelet_nodes") > 500
+    assert sc.stat("node_mode") == (2 if lds else 1) and (sc.stat("treelet_nodes") > 500) == (lds == 2)
     sc.iterations = bounces
     sc.render(spp)
     fr, segs = oracle_render(oracle, osc, spec, W, H, bounces, spp)
@@ -650,13 +651,13 @@ def test_closest_hit_unit_level_mesh(api, oracle):
     ot0 = np.where(h0["t"] > 0, h0["t"], np.float32(-1))
     ot2 = np.where(h2["t"] > 0, h2["t"], np.float32(-1))
     assert same_bits(ot0, ot2)
-    for policy, lds, treelet in ((0, 2, -1), (0, 2, 64), (0, 0, -1), (4, 2, -1), (4, 0, -1)):
+    for policy, lds, treelet in ((0, 2, -1), (0, 2, 64), (0, 2, 0), (4, 2, -1), (4, 2, 0)):
         sc = api.Scene(16, 16)
         sc.set_option("bvh_policy", policy)
         sc.set_option("treelet", treelet)
         sc.set_option("lds_scene", lds)
         sc.load(spec)
-        assert sc.stat("node_mode") == (2 if lds else 1)
+        assert sc.stat("node_mode") == (2 if treelet else 1)
         t, tri = sc.debug_closest_hit(rays)
         assert same_bits(t, ot2), "bvh_policy %d lds_scene %d treelet %d" % (policy, lds, treelet)
         assert (tri >= 0).sum() > 2500
@@ -790,11 +791,12 @@ def test_config3_mesh_through_add_obj(api, oracle, tmp_path):
     W, H = 96, 64
     sc, verts, mati = _mesh100k_from_obj(api, oracle, tmp_path, W, H)
     tris, mats, objs = sc.debug_scene()
+    assert sc.stat("flat_triangles") == 12               # the authored walls: in front of the tree
     assert objs.tolist() == [0, 12] and tris.shape[0] == 12 + verts.shape[0] > 100000
     assert tris[12:].tobytes() == api.triangles_from_vertices(verts, mati).tobytes()
     for k, mi in enumerate((scenes.WHITE_DIFFUSE, scenes.CHROMIUM, scenes.GLASS)):
         assert mats[10 + k].tobytes() == api.Material(*scenes.BUILTIN_MATERIALS[mi])[0].tobytes()
-    assert sc.stat("node_mode") == 2                     # treelet staged in LDS
+    assert sc.stat("node_mode") == 1                     # 50 k nodes: read through L1/L2
     osc = oracle.OracleScene()
     for m in list(scenes.BUILTIN_MATERIALS) + [scenes.BUILTIN_MATERIALS[i] for i in (scenes.WHITE_DIFFUSE, scenes.CHROMIUM, scenes.GLASS)]:
         osc.add_Material(*m)
@@ -814,7 +816,7 @@ def test_config3_mesh_through_add_obj(api, oracle, tmp_path):
 
 def test_full_size_properties_mesh_1080p(api, oracle, tmp_path):
     """BASELINE config 3 at full size (OBJ-loaded MESH-100k, 1920x1080, 8 bounces): k samples in one launch
-    == k launches of one == the same under the other schedule / another suspension threshold / with every node through L1/L2; the union of
+    == k launches of one == the same under the other schedule / another suspension threshold; the union of
     two ranks' tiles == the single-context frame."""
     W, H, B = 1920, 1080, 8
     a, _, _ = _mesh100k_from_obj(api, oracle, tmp_path, W, H)
@@ -823,7 +825,7 @@ def test_full_size_properties_mesh_1080p(api, oracle, tmp_path):
     ca, ra = a.read_colors(), a.read_rnds()
     assert float(ca[:, :3].sum()) > 0
     del a
-    for opts in ({"steps": 3}, {"schedule": 0}, {"suspend_lanes": 8}, {"lds_scene": 0}):
+    for opts in ({"steps": 3}, {"schedule": 0}, {"suspend_lanes": 8}):
         b, _, _ = _mesh100k_from_obj(api, oracle, tmp_path, W, H)
         steps = opts.pop("steps", 1)
         for k, v in opts.items():

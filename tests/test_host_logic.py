@@ -65,7 +65,7 @@ def test_treelet_reindexing(api, ntris, want):
     assert sorted(orig.tolist()) == list(range(spec.ntris))
     assert sc.stat("flat_triangles") == 12
     bvh_check.validate_structure(nodes, tris, spec.ntris, 12)
-    if want == 0:
+    if want == 0:             # the default
         assert T == 0 and sc.stat("node_mode") == 1
         return
     assert sc.stat("node_mode") == 2
