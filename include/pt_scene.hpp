@@ -103,6 +103,29 @@ public:
         ck(pt_read_colors(ctx, &out[0].s[0], n));
         return out;
     }
+    // what the reference shows through its GL blit (main.cpp:1019-1039), as files
+    void write_ppm(const std::string& path, int which = 0) { ck(pt_write_ppm(ctx, path.c_str(), which)); }
+    void write_pfm(const std::string& path) { ck(pt_write_pfm(ctx, path.c_str())); }
+    // multi-GPU hosts: init_Scene_tiled instead of init_Scene, then comm_init with the
+    // 128-byte id rank 0 obtained from Scene::comm_unique_id(), render as usual, gather_frame() + download_frame()
+    void init_Scene_tiled(int device, int rank, int world, int rows_per_block = 8) {
+        if (pt_create_tiled(device, globals.screen_width, globals.screen_height, rank, world, rows_per_block, &ctx) != PT_OK)
+            throw std::runtime_error(std::string("init_Scene_tiled: ") + pt_last_error(nullptr));
+    }
+    static std::vector<unsigned char> comm_unique_id() {
+        std::vector<unsigned char> id(PT_COMM_ID_BYTES);
+        if (pt_comm_unique_id(id.data()) != PT_OK) throw std::runtime_error(std::string("comm_unique_id: ") + pt_last_error(nullptr));
+        return id;
+    }
+    void comm_init(const std::vector<unsigned char>& id) { ck(pt_comm_init(ctx, id.data())); }
+    void gather_frame() { ck(pt_gather_frame(ctx)); }
+    std::vector<cl_float3> download_frame() {
+        int64_t n = 0;
+        ck(pt_frame_size(ctx, nullptr, nullptr, &n));
+        std::vector<cl_float3> out((size_t)n);
+        ck(pt_read_frame(ctx, &out[0].s[0], n));
+        return out;
+    }
     pt_context* handle() { return ctx; }
 
 private:

@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < samples; ++i) scene.render();          // onIdle, main.cpp:1226
         scene.finish();
         std::vector<cl_float3> colors = scene.download_colors();
+        if (argc > 4) scene.write_ppm(argv[4]);                      // what onDisplay() would have shown (main.cpp:1019-1039)
         unsigned long long h = 1469598103934665603ull;
         for (const cl_float3& c : colors)
             for (int k = 0; k < 3; ++k) {

@@ -365,7 +365,11 @@ def test_cpp_dropin_host_program(oracle):
     exe = os.path.join(os.path.dirname(__file__), "cpp", "dropin")
     assert os.path.exists(exe), "run `make` first"
     W, H, S = 72, 40, 3
-    out = subprocess.run([exe, str(W), str(H), str(S)], check=True, capture_output=True, text=True).stdout
+    import tempfile
+    ppm = os.path.join(tempfile.mkdtemp(), "dropin.ppm")
+    out = subprocess.run([exe, str(W), str(H), str(S), ppm], check=True, capture_output=True, text=True).stdout
+    head = open(ppm, "rb").read(15).split(b"\n")
+    assert head[0] == b"P6" and head[1] == b"%d %d" % (W, H)
     line = [ln for ln in out.splitlines() if ln.startswith("samples")][0].split()
     assert int(line[1]) == S
     sc = oracle.OracleScene()
