@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <mutex>
 #include <string>
 
 namespace ptamd {
@@ -32,9 +33,7 @@ struct RcclApi {
     std::string error;
 };
 
-RcclApi* rccl() {
-    static RcclApi api;
-    if (api.handle || !api.error.empty()) return &api;
+void bind_rccl(RcclApi& api) {
     const char* resident[] = {"librccl.so", "librccl.so.1"};
     for (const char* n : resident)
         if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // the copy this process already uses
@@ -43,7 +42,7 @@ RcclApi* rccl() {
         if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (!api.handle) {
         api.error = std::string("librccl not found: ") + dlerror();
-        return &api;
+        return;
     }
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
@@ -52,6 +51,12 @@ RcclApi* rccl() {
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString)
         api.error = "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather/ncclGetErrorString";
+}
+
+RcclApi* rccl() {          // bound once, whichever host thread (one per context) asks first
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] { bind_rccl(api); });
     return &api;
 }
 
