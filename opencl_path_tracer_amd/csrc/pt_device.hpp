@@ -309,7 +309,6 @@ struct Trav {
     char* tos;     // top of this lane's stack (entry 0 = sentinel kDone), as a byte address
     int stride;    // bytes between entries
     int cur;
-    int k;         // single-step schedules: next triangle of the current leaf
     int pend;      // round(): a leaf met during the node phase and not yet intersected (0: none)
     int onx, ony, onz;   // byte offset of the entry-plane pair of each axis inside a staged node; 8 / 24 / 40 = direction negative
     f3 cn, cf;           // -(P * inv) widened down / up (entry / exit distance = fma(plane, inv, c))
@@ -331,7 +330,6 @@ struct Trav {
         stride = stk.stride * (int)sizeof(StackT);
         *reinterpret_cast<StackT*>(tos) = (StackT)kDone;
         cur = 0;        // the root is always an interior node
-        k = 0;
         pend = 0;
     }
     PT_DEV void setup(f3 P_, f3 D_) {
@@ -464,12 +462,6 @@ struct Trav {
         }
     }
 
-    // one visit of whichever kind the current node needs (flat single-step loops; no deferred leaf)
-    template <bool COUNT>
-    PT_DEV void node_step_any(const SceneView& sv, WorkCount* wc) {
-        node_step<COUNT, false, MODE == kNodesLds ? kVisitLds : MODE == kNodesGlobal ? kVisitGlobal : kVisitFlat>(sv, wc);
-    }
-
     // exact test of packed triangle ti against the ray, keeping the closest (ties: lower rank)
     template <bool COUNT>
     PT_DEV void tri_step(const SceneView& sv, int ti, WorkCount* wc) {
@@ -523,11 +515,6 @@ struct Trav {
         }
     }
 
-    PT_DEV void pop() {
-        cur = (int)*reinterpret_cast<const StackT*>(tos);
-        tos -= stride;
-    }
-
     template <bool COUNT>
     PT_DEV void round(const SceneView& sv, WorkCount* wc) {
         if (MODE == kNodesLds) {
@@ -550,18 +537,6 @@ struct Trav {
             for (int j = 0; j < count; ++j) tri_step<COUNT>(sv, first + j, wc);
             cur = popped;
             tos -= stride;
-        }
-    }
-
-    // one triangle of the current leaf (single-step schedules)
-    template <bool COUNT>
-    PT_DEV void leaf_step(const SceneView& sv, WorkCount* wc) {
-        const int v = leaf_bits(cur);
-        const int first = v >> 3, count = (v & 7) + 1;
-        tri_step<COUNT>(sv, first + k, wc);
-        if (++k >= count) {
-            k = 0;
-            pop();
         }
     }
 };

@@ -11,9 +11,10 @@ namespace ptamd {
 // every local pixel.  generate -> for each bounce { intersect ; shade } with the path state SoA in
 // HBM (WfParams) and index queues between the stages.
 //   wf_generate : 2 LCG draws + camera ray per pixel (prog.cl:384-389), state init (prog.cl:307-316)
-//   wf_intersect: each wave owns 256 consecutive entries of a ray queue and refills a lane as soon
-//                 as its traversal ends (__ballot/__popcll rank inside the wave's range), so no
-//                 lane idles while its neighbours finish long traversals.  At the end the block
+//   wf_intersect: each wave owns 256 consecutive entries of a ray queue; it runs the big-triangle list over
+//                 them with all lanes busy, then traverses in trips of while-while rounds, refilling the
+//                 lanes whose traversal ended between trips (__ballot/__popcll rank inside the wave's
+//                 range) while the stragglers carry on.  At the end of its range the block
 //                 compacts its rays into three class queues by the material type they hit
 //                 (order-preserving ballot scan through LDS, 3 global atomics per 1,024 rays).
 //   wf_shade    : one block row per class -> waves are material-coherent.  Survivors go to the
@@ -123,11 +124,11 @@ __global__ void __launch_bounds__(256) wf_generate(WfParams w) {
 // Rays per wave: each wave owns a contiguous range of the bounce's ray stream (no global atomics
 // on the fetch side; blocks that finish early are replaced by the dispatcher).
 constexpr int kWfRaysPerWave = 256;
+constexpr int kWfSuspendLanes = 48;     // 8 / 16 / 32 / 48 -> 749 / 752 / 763 / 773 Msamples/s (flat loop 700)
 
-// Flat traversal loop: every iteration each lane performs at most one node visit and then at most
-// one triangle test, and a lane whose ray is finished takes the next ray of the wave's range in the
-// SAME iteration (the next ray's 32 B are prefetched one assignment ahead, so the switch costs no
-// memory round trip).  No lane ever waits for another lane's traversal to end.
+// Traversal with lane refill: a trip = while-while rounds until most lanes are done; a lane whose ray is
+// finished takes the next ray of the wave's range before the next trip (the next ray's 32 B are prefetched one
+// assignment ahead, so the switch costs no memory round trip); the stragglers simply carry on.
 template <int MODE, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
     typedef typename StackOf<MODE>::type StackT;
@@ -202,9 +203,16 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
                 cbase = min(cbase + (unsigned)__popcll(want), cend);
             }
             if (__ballot(!tr.done() || npos != ~0u) == 0) break;
-            // ---- one node visit, then one triangle test
-            if (tr.is_node(tr.cur)) tr.template node_step_any<false>(sv, &wc);
-            if (tr.is_leaf(tr.cur)) tr.template leaf_step<false>(sv, &wc);
+            // ---- while-while rounds until at most kWfSuspendLanes lanes are unfinished (and one has finished): the
+            // megakernel's tail suspension, with the refill from the ray stream above in the place of shading.
+            // (A flat loop -- one node visit and one triangle test per lane and iteration -- ran both bodies every
+            // iteration: intersect-only rate 1,256 -> 1,501 Msamples/s-equivalent with rounds, profiles/r02/u_*.)
+            for (;;) {
+                tr.template round<false>(sv, &wc);
+                const unsigned long long unfinished = __ballot(!tr.done());
+                if (unfinished == 0) break;
+                if (__popcll(unfinished) <= kWfSuspendLanes && __ballot(tr.done() && pos != ~0u) != 0) break;
+            }
             // ---- finished: hit record + class byte
             if (tr.done() && pos != ~0u) {
                 hits[pos] = make_float2(tr.best_t, __int_as_float(tr.best));
