@@ -178,6 +178,8 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *                  lanes of a wave start a sample together; -1 (default) 1 when the context has >= 3 tiles per
  *                  resident wave (one or two GPUs at 1080p), else 0
  *   "suspend_lanes" -1 (default: 16 with the whole tree in LDS, otherwise 24), 0..63
+ *   "waves_per_simd" kernels that read nodes from global memory: register budget for 4, 5 or 6 resident waves per SIMD
+ *                  (128 / 96 / 80 VGPRs); -1 (default) the most that the per-lane stacks in LDS leave room for
  *   "persistent"   1 (default) megakernel grid only fills the chip and every wave pulls its next 8x8
  *                  tile from a global counter; 0 one workgroup per group of tiles
  *   "chunk_spp"    persistent megakernel work items: n > 0 (pass, tile) items of n samples, chained per tile
@@ -191,8 +193,8 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *   "debug_repeat" 0..1000 extra timed launches in pt_debug_closest_hit */
 int pt_set_option(pt_context* ctx, const char* key, int64_t value);
 /* stats: "segments" path segments executed since the last reset, "samples", "kernel_ms" (sum of
- * HIP-event durations of the dominant kernel), "kernel_launches", "bvh_nodes", "bvh_depth",
- * "bvh_build_ms", "bvh_on_device", "triangles", "lds_bytes", "node_mode" (0 whole tree in LDS, 1 L1/L2 only,
+ * HIP-event durations of the dominant kernel), "kernel_launches", "bvh_nodes", "bvh_depth", "stack_entries" (per-lane traversal stack: deepest interior node + 2),
+ * "bvh_build_ms", "bvh_on_device", "triangles", "lds_bytes", "waves_per_simd", "node_mode" (0 whole tree in LDS, 1 L1/L2 only,
  * 2 treelet), "treelet_nodes", "flat_triangles", and with count_work: "node_visits", "tri_tests", "wave_node_steps",
  * "wave_tri_steps", "tile_lane_steps" */
 int pt_get_stat(pt_context* ctx, const char* key, double* out);

@@ -64,6 +64,7 @@ struct pt_context {
     std::vector<TriMeta> meta;
     std::vector<int32_t> orig;
     int bvh_depth = 0;
+    int interior_depth = 0;   // depth of the deepest interior node of the packed tree (root: 0): sizes the traversal stacks
     int n_flat = 0;             // packed triangles [0, n_flat): the big-triangle list tested before the tree
 
     // ---- device buffers
@@ -107,6 +108,7 @@ struct pt_context {
     int flat_list = 16;        // at most this many big triangles go to the flat list (option flat_list; 0: none)
     int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
     int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 16 with the whole tree in LDS, else 24)
+    int waves_per_simd = -1; // nodes from global memory: register budget for 4 / 5 / 6 waves per SIMD (-1: the most the LDS stacks allow)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
     int bvh_policy = 0;   // 0/1 host SAH with SAH leaf termination, 2 leaves of <= 4, 3 leaves of <= 8, 4 device LBVH
@@ -117,6 +119,7 @@ struct pt_context {
     double kernel_ms_acc = 0.0;
     int64_t kernel_launches = 0;
     size_t last_lds_bytes = 0;
+    int last_waves_per_simd = 4;
 
     std::string err;
     char info[256] = {0};
@@ -515,7 +518,26 @@ void compute_cost_boxes_impl(pt_context* ctx) {
 
 // Stack entries a traversal of this tree needs: sentinel + one far child per level + the slot above the top
 // that Trav::node_step writes unconditionally (+ 2 spare), rounded to even.
-int stack_entries_for(int bvh_depth) { return std::min(kStackEntries, ((bvh_depth + 4) + 1) & ~1); }
+// Entries of a lane's traversal stack.  A visit of an interior node at depth d (root: 0) finds at most d far children
+// pushed by its ancestors above the sentinel (entry 0) and stores its own far child one above the top, at index
+// <= d + 1, whether or not it keeps it (Trav::node_step); leaves store nothing.  So the deepest interior node's
+// depth + 2 entries suffice; rounded up to an even count.  Every entry is LDS that bounds the resident waves of the
+// kernels reading nodes from global memory (launch_cfg), so the bound is the exact one, measured on the packed tree.
+int deepest_interior_node(const std::vector<Node64>& nodes) {
+    int deepest = 0;
+    std::vector<std::pair<int32_t, int>> todo;
+    if (!nodes.empty()) todo.emplace_back(0, 0);
+    while (!todo.empty()) {
+        const std::pair<int32_t, int> it = todo.back();
+        todo.pop_back();
+        deepest = std::max(deepest, it.second);
+        const Node64& nd = nodes[(size_t)it.first];
+        if (nd.left >= 0) todo.emplace_back(nd.left, it.second + 1);
+        if (nd.right >= 0) todo.emplace_back(nd.right, it.second + 1);
+    }
+    return deepest;
+}
+int stack_entries_for(int interior_depth) { return std::min(kStackEntries, ((interior_depth + 2) + 1) & ~1); }
 
 constexpr size_t kLdsPerCu = 160 * 1024;
 // next to the stacks and the staged nodes: the big-triangle list (96 B each) and, in wf_intersect, one class byte per ray
@@ -523,9 +545,9 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 constexpr size_t kLdsSlack = 32 * 96 + 4096 + 1024 + 256;
 
 // Does the whole tree fit next to two 512-thread workgroups per CU (kNodesLds: 16-bit references)?
-bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int bvh_depth) {
+bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int interior_depth) {
     const bool s16 = n_nodes <= 32767 && n_tris <= 4096;
-    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(bvh_depth) * 2 * 512 + 32 * 96 + 32 <= kLdsPerCu / 2;   // (+ flat list: packet + box per triangle)
+    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(interior_depth) * 2 * 512 + 32 * 96 + 32 <= kLdsPerCu / 2;   // (+ flat list: packet + box per triangle)
 }
 
 // Treelet: when the tree is too large for LDS, the T nodes with the largest boxes --
@@ -533,9 +555,9 @@ bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int bvh_depth) {
 // top of the tree -- are renumbered to [0, T) and every workgroup stages exactly those.  T is what one
 // 1,024-thread workgroup per CU has left next to its 32-bit stacks.  The rest keeps its depth-first order.
 // Returns T (0: no treelet).
-int reindex_treelet(std::vector<Node64>& nodes, int bvh_depth, int want) {
+int reindex_treelet(std::vector<Node64>& nodes, int interior_depth, int want) {
     const size_t n = nodes.size();
-    const size_t stacks = (size_t)stack_entries_for(bvh_depth) * 4 * 1024;
+    const size_t stacks = (size_t)stack_entries_for(interior_depth) * 4 * 1024;
     if (stacks + kLdsSlack + 64 * sizeof(Node64) > kLdsPerCu) return 0;
     size_t cap = (kLdsPerCu - kLdsSlack - stacks) / sizeof(Node64);
     if (want > 0) cap = std::min(cap, (size_t)want);
@@ -575,10 +597,13 @@ int reindex_treelet(std::vector<Node64>& nodes, int bvh_depth, int want) {
     return t_final;
 }
 
-void plan_node_placement(pt_context* ctx) {
+int plan_node_placement(pt_context* ctx) {
     ctx->treelet_nodes = 0;
-    if (ctx->treelet == 0 || whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->bvh_depth)) return;
-    ctx->treelet_nodes = reindex_treelet(ctx->nodes, ctx->bvh_depth, ctx->treelet);
+    ctx->interior_depth = deepest_interior_node(ctx->nodes);
+    if (ctx->interior_depth + 2 > kStackEntries) return fail(ctx, PT_ESCENE, "internal: BVH deeper than the traversal stack");
+    if (ctx->treelet == 0 || whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->interior_depth)) return PT_OK;
+    ctx->treelet_nodes = reindex_treelet(ctx->nodes, ctx->interior_depth, ctx->treelet);
+    return PT_OK;
 }
 
 template <class T>
@@ -623,12 +648,12 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->n_nodes = (int32_t)ctx->nodes.size();
     p->n_tris = (int32_t)ctx->orig.size();
     p->n_flat = ctx->n_flat;
-    p->stack_entries = stack_entries_for(ctx->bvh_depth);
+    p->stack_entries = stack_entries_for(ctx->interior_depth);
     // where the traversal reads nodes from: the whole tree staged in LDS, its re-indexed top, or L1/L2 only
     p->node_mode = kNodesGlobal;
     p->treelet_nodes = 0;
     if (ctx->lds_scene) {
-        if (whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->bvh_depth)) {
+        if (whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->interior_depth)) {
             p->node_mode = kNodesLds;
         } else if (ctx->treelet_nodes > 0) {
             p->node_mode = kNodesTreelet;
@@ -964,8 +989,8 @@ static int build_on_device(pt_context* ctx, bool* done) {
             if (nd.right < 0) nd.right -= nf << 3;
         }
     }
-    plan_node_placement(ctx);
-    int rc = PT_OK;
+    int rc = plan_node_placement(ctx);
+    if (rc != PT_OK) { drop(); return rc; }
     if (nf > 0) {                 // recomposed on the host: replace the builder's device arrays
         (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta);
         if ((rc = upload_vec(ctx, &ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size())) != PT_OK) return rc;
@@ -1006,7 +1031,7 @@ int pt_upload_triangles(pt_context* ctx) {
     ctx->bvh_on_device = 0;
     int rc = build_and_pack(ctx);
     if (rc != PT_OK) return rc;
-    plan_node_placement(ctx);
+    if ((rc = plan_node_placement(ctx)) != PT_OK) return rc;
     ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (ctx->has_device) {
         PT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1055,6 +1080,8 @@ int pt_upload_seeds(pt_context* ctx, const int32_t* seeds, int64_t n) {
     return seed_upload(ctx, seeds);
 }
 
+static int ptamd_resident_waves(const pt_context*, const LaunchConfig& lc) { return lc.persistent_blocks * (lc.block / 64); }
+
 static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc) {
     lc->block = traversal_block(p.node_mode);
     lc->lds_bytes = traversal_lds_bytes(p, lc->block);
@@ -1064,11 +1091,18 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
     // their last samples alone -- is on the critical path and lockstep, whose lanes finish together, wins clearly
     // (1080p over 4 / 8 ranks: 87 % / 62 % strong-scaling efficiency against 73 % / 42 %; over 2 ranks suspend wins again:
     // 95.7 % against 88 %; profiles/r02/e_*, q_*).
-    lc->schedule = ctx->schedule >= 0 ? ctx->schedule : (p.n_tiles >= 3 * ctx->cu_count * 16 ? 1 : 0);
-    // resident workgroups at 4 waves per SIMD: 4 x 256 threads (nodes through L1/L2), 2 x 512 (whole tree in
-    // LDS), 1 x 1024 (treelet) per CU
-    lc->persistent_blocks = ctx->cu_count * std::max(1, 1024 / lc->block);
+    // resident workgroups at 4 waves per SIMD: 2 x 512 threads (whole tree in LDS), 1 x 1024 (treelet) per CU; nodes through
+    // L1/L2 (256 threads): as many waves per SIMD -- 6, 5 or 4 -- as the stacks in LDS leave room for
+    lc->waves_per_simd = 4;
+    if (p.node_mode == kNodesGlobal) {
+        const int want = ctx->waves_per_simd > 0 ? ctx->waves_per_simd : 6;
+        for (int w = std::min(want, 6); w > 4; --w)
+            if ((size_t)w * lc->lds_bytes + 1024 <= kLdsPerCu) { lc->waves_per_simd = w; break; }
+    }
+    lc->persistent_blocks = ctx->cu_count * std::max(1, 256 * lc->waves_per_simd / lc->block);
+    lc->schedule = ctx->schedule >= 0 ? ctx->schedule : (p.n_tiles >= 3 * ptamd_resident_waves(ctx, *lc) ? 1 : 0);
     ctx->last_lds_bytes = lc->lds_bytes;
+    ctx->last_waves_per_simd = lc->waves_per_simd;
 }
 
 int pt_generate_rays(pt_context* ctx, const pt_camera* cam) {
@@ -1164,6 +1198,8 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         ctx->current_sample += nsamples;
         return PT_OK;
     }
+    LaunchConfig lc;
+    launch_cfg(ctx, p, &lc);
     if (ctx->persistent) {
         PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counter, 0, sizeof(uint32_t), ctx->stream));
         p.tile_counter = ctx->d_tile_counter;
@@ -1174,7 +1210,7 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         // passes amortise that tail, and half a launch's samples still re-balance the chip -- 64 spp per launch:
         // 8 / 16 / 32 / 64 -> 1689 / 1760 / 1787 / 1761 Msamples/s; 256 spp: 1706 / 1789 / 1843 / 1868
         // (profiles/r02/n_*; the lockstep kernel of round 1 peaked at 8).
-        const int resident_waves = ctx->cu_count * 16;
+        const int resident_waves = ptamd_resident_waves(ctx, lc);
         // fewer tiles per resident wave (1080p over 2 / 4 / 8 GPUs: 4.0 / 2.0 / 1.0): suspend with passes of 16, lockstep with
         // passes of 8, lockstep with whole tiles (profiles/r02/q_*: 95.7 % / 87.5 % / 61.8 % of the one-GPU rate per GPU)
         const int auto_chunk = p.n_tiles >= 6 * resident_waves ? (nsamples >= 256 ? 64 : 32)
@@ -1192,8 +1228,6 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
             p.chunk_spp = chunk;
         }
     }
-    LaunchConfig lc;
-    launch_cfg(ctx, p, &lc);
     EventPair* ep;
     if ((rc = time_begin(ctx, &ep)) != PT_OK) return rc;
     PT_HIP(ctx, launch_render_mega(p, lc, ctx->stream));
@@ -1407,6 +1441,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "suspend_lanes") {
         if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, "suspend_lanes: -1 default, 0..63");
         ctx->suspend_lanes = (int)value;
+    } else if (k == "waves_per_simd") {
+        if (value != -1 && (value < 4 || value > 6)) return fail(ctx, PT_EINVAL, "waves_per_simd: -1 automatic, 4..6 (kernels that read nodes from global memory)");
+        ctx->waves_per_simd = (int)value;
     } else if (k == "debug_repeat") {
         if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "debug_repeat: 0..1000 extra timed launches");
         ctx->debug_repeat = (int)value;
@@ -1437,10 +1474,12 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out) {
     std::string k(key);
     if (k == "bvh_nodes") { *out = (double)ctx->nodes.size(); return PT_OK; }
     if (k == "bvh_depth") { *out = (double)ctx->bvh_depth; return PT_OK; }
+    if (k == "stack_entries") { *out = (double)stack_entries_for(ctx->interior_depth); return PT_OK; }
     if (k == "bvh_build_ms") { *out = ctx->bvh_build_ms; return PT_OK; }
     if (k == "bvh_on_device") { *out = (double)ctx->bvh_on_device; return PT_OK; }
     if (k == "triangles") { *out = (double)ctx->orig.size(); return PT_OK; }
     if (k == "lds_bytes") { *out = (double)ctx->last_lds_bytes; return PT_OK; }
+    if (k == "waves_per_simd") { *out = (double)ctx->last_waves_per_simd; return PT_OK; }
     if (k == "treelet_nodes") { *out = (double)ctx->treelet_nodes; return PT_OK; }
     if (k == "flat_triangles") { *out = (double)ctx->n_flat; return PT_OK; }
     if (k == "node_mode") {      // what the next launch will use: 0 whole tree in LDS, 1 L1/L2 only, 2 treelet

@@ -126,6 +126,7 @@ struct LaunchConfig {
     int persistent_blocks = 1 << 30;   // grid size of a persistent launch (workgroups that fit the chip)
     bool count_work = false;           // also count node visits / triangle tests into stats[2..9]
     int schedule = 0;                  // megakernel: 0 lockstep per sample, 1 restart + tail suspension (pt_kernels.hip)
+    int waves_per_simd = 4;            // register budget of the k_render instance: 4, or 5 / 6 for nodes from global memory
 };
 
 // launchers (pt_kernels.hip, pt_wavefront.hip, pt_debug.hip); all asynchronous on `stream`

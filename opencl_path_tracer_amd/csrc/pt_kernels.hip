@@ -208,8 +208,12 @@ PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, con
 //    reach this wave -- possibly on another XCD -- through an agent-scope release (producer: stores,
 //    L2 write-back, tile_done[tile] = pass + 1) and acquire (consumer: poll, L1 invalidate, loads).
 //    The host guarantees n_pass * n_tiles + (resident waves) < 2^31 (pt_render).
-template <bool SPLIT, int MODE, int BLOCK, bool COUNT, int SCHED>
-__global__ void __launch_bounds__(BLOCK, 4) k_render(RenderParams p) {
+// WPS = waves per SIMD the register budget is set for (512 / WPS VGPRs): 4 where the kernel is bound by VALU
+// issue (nodes in LDS); 5 or 6 for nodes from global memory, where every wave-level step is a dependent memory
+// round trip and a fifth / sixth wave hides more of it than the extra spills cost (MESH-100k +16 %, MESH-1M +13 %;
+// the same step lost 30 % on the Cornell box: profiles/r02/t_*, v_*).
+template <bool SPLIT, int MODE, int BLOCK, bool COUNT, int SCHED, int WPS>
+__global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
     LaneStack<typename StackOf<MODE>::type> stk;
     SceneView sv;
     setup_traversal<MODE, BLOCK>(p, &sv, &stk);
@@ -370,14 +374,14 @@ hipError_t launch_gen_ray(const RenderParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <bool SPLIT, int MODE, int BLOCK, bool COUNT, int SCHED>
+template <bool SPLIT, int MODE, int BLOCK, bool COUNT, int SCHED, int WPS>
 static hipError_t launch_one(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
     const int waves = n_waves(p);
     if (waves == 0) return hipSuccess;
     constexpr int wpb = BLOCK / 64;
     int blocks = (waves + wpb - 1) / wpb;
     if (p.tile_counter) blocks = std::min(blocks, lc.persistent_blocks);
-    auto kern = k_render<SPLIT, MODE, BLOCK, COUNT, SCHED>;
+    auto kern = k_render<SPLIT, MODE, BLOCK, COUNT, SCHED, WPS>;
     if (lc.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc.lds_bytes);
         if (e != hipSuccess) return e;
@@ -390,9 +394,12 @@ template <bool SPLIT, bool COUNT, int SCHED>
 static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
     if (lc.block != traversal_block(p.node_mode)) return hipErrorInvalidValue;
     switch (p.node_mode) {
-    case kNodesLds: return launch_one<SPLIT, kNodesLds, 512, COUNT, SCHED>(p, lc, stream);
-    case kNodesGlobal: return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED>(p, lc, stream);
-    case kNodesTreelet: return launch_one<SPLIT, kNodesTreelet, 1024, COUNT, SCHED>(p, lc, stream);
+    case kNodesLds: return launch_one<SPLIT, kNodesLds, 512, COUNT, SCHED, 4>(p, lc, stream);
+    case kNodesGlobal:
+        if (lc.waves_per_simd == 6) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 6>(p, lc, stream);
+        if (lc.waves_per_simd == 5) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 5>(p, lc, stream);
+        return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 4>(p, lc, stream);
+    case kNodesTreelet: return launch_one<SPLIT, kNodesTreelet, 1024, COUNT, SCHED, 4>(p, lc, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -41,6 +41,9 @@ def test_bvh_structure(api, cb_spec):
     assert orig[:12].tolist() == list(range(12))
     depth = bvh_check.validate_structure(nodes, tris, 1932, 12)
     assert depth <= sc.stat("bvh_depth") <= 30
+    # the traversal stack (LDS, [entry][lane]) is sized by the exact bound: sentinel + one far child per interior
+    # level above the visited node + the slot a visit stores into above the top
+    assert sc.stat("stack_entries") == ((depth + 2) + 1) & ~1
     # packets hold exactly the twelve floats prog.cl:94-112 reads, in add order via `orig`
     verts = np.concatenate([v for v, _ in cb_spec.objects]).reshape(-1, 9)
     assert np.array_equal(tris[:, :9], verts[orig])
@@ -69,8 +72,8 @@ def test_treelet_reindexing(api, ntris, want):
         assert T == 0 and sc.stat("node_mode") == 1
         return
     assert sc.stat("node_mode") == 2
-    depth = int(sc.stat("bvh_depth"))
-    entries = min(36, ((depth + 4) + 1) & ~1)
+    entries = int(sc.stat("stack_entries"))
+    assert bvh_check.validate_structure(nodes, tris, spec.ntris, 12) + 2 <= entries <= 36
     cap = (160 * 1024 - (32 * 96 + 4096 + 1024 + 256) - entries * 4 * 1024) // 64      # kLdsSlack: flat list + wf_intersect's arrays
     assert T == min(cap if want < 0 else min(cap, want), nodes.shape[0]) and T >= 2
     left, right = nodes[:, 12].view(np.int32), nodes[:, 13].view(np.int32)
