@@ -7,7 +7,7 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-s
 
 all: $(PKG)/libptamd.so oracle tests/cpp/dropin
 
-SRCS    := $(CSRC)/pt_host.cpp $(CSRC)/pt_obj.cpp $(CSRC)/pt_kernels.hip $(CSRC)/pt_wavefront.hip $(CSRC)/pt_debug.hip $(CSRC)/pt_lbvh.hip $(CSRC)/pt_comm.hip $(CSRC)/pt_image.cpp
+SRCS    := $(CSRC)/pt_host.cpp $(CSRC)/pt_obj.cpp $(CSRC)/pt_kernels.hip $(CSRC)/pt_wavefront.hip $(CSRC)/pt_debug.hip $(CSRC)/pt_lbvh.hip $(CSRC)/pt_comm.hip $(CSRC)/pt_image.cpp $(CSRC)/pt_wide.cpp
 HDRS    := $(CSRC)/pt_internal.hpp $(CSRC)/pt_device.hpp include/pt_api.h
 OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 

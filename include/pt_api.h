@@ -178,6 +178,11 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *                  lanes of a wave start a sample together; -1 (default) 1 when the context has >= 3 tiles per
  *                  resident wave (one or two GPUs at 1080p), else 0
  *   "suspend_lanes" -1 (default: 16 with the whole tree in LDS, otherwise 24), 0..63
+ *   "wide_nodes"   trees read from global memory as 4-wide nodes with 8-bit child boxes (one 64-byte fetch decides two
+ *                  BVH2 levels): 1 (default) when the tree does not fit LDS, 0 never, 2 every tree; set before the
+ *                  triangles are uploaded
+ *   "wide_lds_entries" 4-wide traversal: per-lane stack entries kept in LDS (default 24; the rest of the worst case lives in
+ *                  global memory and is touched only by rays that get there); even, 4..24; set before the triangles are uploaded
  *   "waves_per_simd" kernels that read nodes from global memory: register budget for 4, 5 or 6 resident waves per SIMD
  *                  (128 / 96 / 80 VGPRs); -1 (default) the most that the per-lane stacks in LDS leave room for
  *   "persistent"   1 (default) megakernel grid only fills the chip and every wave pulls its next 8x8
@@ -195,7 +200,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value);
 /* stats: "segments" path segments executed since the last reset, "samples", "kernel_ms" (sum of
  * HIP-event durations of the dominant kernel), "kernel_launches", "bvh_nodes", "bvh_depth", "stack_entries" (per-lane traversal stack: deepest interior node + 2),
  * "bvh_build_ms", "bvh_on_device", "triangles", "lds_bytes", "waves_per_simd", "node_mode" (0 whole tree in LDS, 1 L1/L2 only,
- * 2 treelet), "treelet_nodes", "flat_triangles", and with count_work: "node_visits", "tri_tests", "wave_node_steps",
+ * 2 treelet, 3 4-wide nodes through L1/L2), "treelet_nodes", "wide_nodes" (how many 4-wide nodes), "flat_triangles", and with count_work: "node_visits", "tri_tests", "wave_node_steps",
  * "wave_tri_steps", "tile_lane_steps" */
 int pt_get_stat(pt_context* ctx, const char* key, double* out);
 
@@ -204,6 +209,10 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out);
  * {rank, mati} pairs, and the add-order index of every packed triangle. */
 int pt_debug_bvh_sizes(const pt_context* ctx, int64_t* nnodes, int64_t* ntris);
 int pt_debug_bvh_copy(const pt_context* ctx, float* nodes, float* tris, int32_t* meta, int32_t* orig);
+/* the 4-wide quantised nodes built from that tree (64 B each: {origin.xyz, exponents | nchild << 24}, {qlo_x, qhi_x,
+ * qlo_y, qhi_y}, {qlo_z, qhi_z, -, -}, {4 child references}); *count = how many there are (0: not built), at most
+ * `capacity` are copied */
+int pt_debug_wide_nodes(const pt_context* ctx, void* out, int64_t capacity, int64_t* count);
 /* Closest hit of n caller-supplied rays through the device traversal (kd_intersect, prog.cl:144-184):
  * out_t[i] = t (-1 on a miss), out_tri[i] = add-order index of the triangle hit (-1 on a miss). */
 int pt_debug_closest_hit(pt_context* ctx, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri);

@@ -29,6 +29,9 @@ PT_COMM_ID_BYTES = 128
 MATERIAL = np.dtype([("kd", "<f4", 4), ("ks", "<f4", 4), ("emission", "<f4", 4), ("F0", "<f4", 4),
                      ("n", "<f4"), ("shininess", "<f4"), ("type", "<i4"), ("_pad", "<i4")])
 RAY = np.dtype([("P", "<f4", 4), ("D", "<f4", 4)])
+# Node4q (csrc/pt_internal.hpp): byte k of a q word is child k's plane on the node's grid, plane = origin + q * 2^(exp - 127)
+WIDE_NODE = np.dtype([("origin", "<f4", 3), ("exp", "u1", 3), ("nchild", "u1"), ("q", "u1", (6, 4)), ("spare", "<u4", 2), ("ref", "<i4", 4)])
+assert WIDE_NODE.itemsize == 64
 TRIANGLE = np.dtype([("r1", "<f4", 4), ("r2", "<f4", 4), ("r3", "<f4", 4), ("N", "<f4", 4),
                      ("mati", "<u2"), ("_pad", "u1", 14)])
 CAMERA = np.dtype([("eye", "<f4", 4), ("lookat", "<f4", 4), ("up", "<f4", 4), ("right", "<f4", 4),
@@ -43,7 +46,7 @@ EXPORTS = [
     "pt_generate_rays", "pt_trace_rays", "pt_render", "pt_set_current_sample", "pt_get_current_sample", "pt_sync",
     "pt_local_pixel_count", "pt_local_pixel_ids", "pt_read_colors", "pt_read_rnds", "pt_read_rays",
     "pt_resolve_ldr", "pt_bind_framebuffer", "pt_device_colors", "pt_device_rnds", "pt_set_stream",
-    "pt_set_option", "pt_get_stat", "pt_debug_bvh_sizes", "pt_debug_bvh_copy", "pt_debug_encounter_rank",
+    "pt_set_option", "pt_get_stat", "pt_debug_bvh_sizes", "pt_debug_bvh_copy", "pt_debug_wide_nodes", "pt_debug_encounter_rank",
     "pt_debug_scene_sizes", "pt_debug_scene_copy", "pt_debug_closest_hit",
     "pt_slab_pixel_count", "pt_frame_size", "pt_comm_unique_id", "pt_comm_init", "pt_gather_frame", "pt_device_frame", "pt_read_frame",
     "pt_write_pfm", "pt_write_ppm", "pt_image_write_pfm", "pt_image_write_ppm", "pt_debug_gather_index", "pt_debug_deinterleave",
@@ -107,6 +110,7 @@ def _load():
     sig("pt_get_stat", C.c_int, vp, C.c_char_p, C.POINTER(C.c_double))
     sig("pt_debug_bvh_sizes", C.c_int, vp, C.POINTER(i64), C.POINTER(i64))
     sig("pt_debug_bvh_copy", C.c_int, vp, vp, vp, vp, vp)
+    sig("pt_debug_wide_nodes", C.c_int, vp, vp, i64, C.POINTER(i64))
     sig("pt_debug_encounter_rank", C.c_int, vp, vp, i64)
     sig("pt_debug_scene_sizes", C.c_int, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64))
     sig("pt_debug_scene_copy", C.c_int, vp, vp, vp, vp)
@@ -427,6 +431,15 @@ class Scene:
         orig = np.zeros(nt.value, dtype=np.int32)
         self._ck(LIB.pt_debug_bvh_copy(self._h, _ptr(nodes), _ptr(tris), _ptr(meta), _ptr(orig)))
         return nodes, tris, meta, orig
+
+    def debug_wide_nodes(self):
+        """The 4-wide quantised nodes (pt_wide.cpp) as a structured array; empty when they were not built."""
+        n = C.c_int64()
+        self._ck(LIB.pt_debug_wide_nodes(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=WIDE_NODE)
+        if n.value:
+            self._ck(LIB.pt_debug_wide_nodes(self._h, _ptr(out), n.value, C.byref(n)))
+        return out
 
     def debug_scene(self):
         nt, nm, no = C.c_int64(), C.c_int64(), C.c_int64()

@@ -33,6 +33,7 @@ static hipError_t launch_debug_t(const RenderParams& p, const pt_ray* rays, int6
     }
     const long long need = (n + BLOCK - 1) / BLOCK;
     const int blocks = (int)std::min<long long>(need, (long long)cu_count * (2048 / BLOCK));
+    if (p.stack_ovf && (long long)blocks * BLOCK > (long long)p.stack_ovf_lanes) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), lds, stream, p, rays, (long long)n, out_t, out_tri);
     return hipGetLastError();
 }
@@ -42,6 +43,7 @@ hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, i
     switch (p.node_mode) {
     case kNodesLds: return launch_debug_t<kNodesLds, 512>(p, rays, n, out_t, out_tri, cu_count, stream);
     case kNodesGlobal: return launch_debug_t<kNodesGlobal, 256>(p, rays, n, out_t, out_tri, cu_count, stream);
+    case kNodesWide: return launch_debug_t<kNodesWide, 256>(p, rays, n, out_t, out_tri, cu_count, stream);
     case kNodesTreelet: return launch_debug_t<kNodesTreelet, 1024>(p, rays, n, out_t, out_tri, cu_count, stream);
     }
     return hipErrorInvalidValue;

@@ -223,6 +223,11 @@ struct SceneView {
     int n_flat;                // packets [0, n_flat): big triangles kept out of the tree, tested first (flat_pass)
     const float4* lds_flat;    // their packets, staged in LDS
     const char* lds_fbox;      // their padded boxes, 48 B each: per axis {lo, hi, hi, lo} (planes picked by address, like a staged node)
+    // kNodesWide: the lane's stack continues in global memory past its LDS entries (a 4-wide traversal can have three
+    // children pending per level, far more than it usually has; LDS holds what keeps six waves per SIMD resident)
+    const char* stk_end;       // the lane's first stack address past its LDS entries
+    unsigned* ovf;             // entry (LDS entries + j) of this lane = ovf[j * ovf_stride]
+    unsigned ovf_stride;
 };
 
 // prog.cl:94-112 on one packet; returns t (> 0) or -1.  `limit` is the current closest t: a
@@ -462,6 +467,98 @@ struct Trav {
         }
     }
 
+    // One visit of a 4-wide node (Node4q, pt_internal.hpp; built by pt_wide.cpp): ONE 64-byte fetch decides what two
+    // BVH2 levels decide.  The child planes are bytes on the node's own grid; a plane decodes as
+    // fma((float)q, step, origin) -- the very expression the host checked to lie outside the child's box -- and then
+    // goes through the same slab test as a BVH2 plane (entry / exit picked by the direction sign, here by selecting
+    // the WORD that holds the four children's bytes: 6 selects for 24 planes).  The children that are hit are sorted
+    // by entry distance (5 compare-exchanges); the nearest is visited next, the others are stored above the top of
+    // the stack farthest first.  All three stores are unconditional (a child that was missed lands above the new
+    // top, where it is never read), so the stack has room for top + 3 at every visit (wide_stack_entries()).
+    // stack entry at address `at`, which may lie past the lane's LDS entries (kNodesWide only)
+    PT_DEV int stack_get(const SceneView& sv, const char* at) const {
+        const int d = (int)(at - sv.stk_end);
+        if (MODE != kNodesWide || d < 0) return (int)*reinterpret_cast<const StackT*>(at);
+        return (int)sv.ovf[(size_t)(d >> (31 - __builtin_clz(stride))) * sv.ovf_stride];      // (stride = 256 lanes x 4 B)
+    }
+    PT_DEV void stack_put(const SceneView& sv, char* at, int v) const {
+        const int d = (int)(at - sv.stk_end);
+        if (MODE != kNodesWide || d < 0) *reinterpret_cast<StackT*>(at) = (StackT)v;
+        else sv.ovf[(size_t)(d >> (31 - __builtin_clz(stride))) * sv.ovf_stride] = (unsigned)v;
+    }
+
+    template <bool COUNT>
+    PT_DEV void wide_step(const SceneView& sv, WorkCount* wc) {
+        const float kWiden = 1.0000005f;
+        // does any lane of the wave come within three entries of the end of its LDS part?  (rare: then every stack
+        // access of this visit goes through the checked accessors)
+        const bool tight = __ballot(tos + 3 * stride >= sv.stk_end) != 0;
+        const int top = tight ? stack_get(sv, tos) : (int)*reinterpret_cast<const StackT*>(tos);
+        if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; }
+        const char* nb = reinterpret_cast<const char*>(sv.nodes);
+        const unsigned off = (unsigned)cur << 6;
+        const float4 h = *reinterpret_cast<const float4*>(nb + off);
+        const uint4 qa = *reinterpret_cast<const uint4*>(nb + (off + 16u));
+        const uint2 qb = *reinterpret_cast<const uint2*>(nb + (off + 32u));
+        const int4 rf = *reinterpret_cast<const int4*>(nb + (off + 48u));
+        const unsigned eb = (unsigned)__float_as_int(h.w);
+        const float sx = __int_as_float((int)((eb & 0xffu) << 23)), sy = __int_as_float((int)(((eb >> 8) & 0xffu) << 23));
+        const float sz = __int_as_float((int)(((eb >> 16) & 0xffu) << 23));
+        const bool ngx = onx == 8, ngy = ony == 24, ngz = onz == 40;
+        const unsigned enx = ngx ? qa.y : qa.x, exx = ngx ? qa.x : qa.y;
+        const unsigned eny = ngy ? qa.w : qa.z, exy = ngy ? qa.z : qa.w;
+        const unsigned enz = ngz ? qb.y : qb.x, exz = ngz ? qb.x : qb.y;
+        const float lim = best_t * kWiden;
+        float key[4];
+        int ref[4] = {rf.x, rf.y, rf.z, rf.w};
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float pnx = fmaf_((float)((enx >> (8 * k)) & 0xffu), sx, h.x), pfx = fmaf_((float)((exx >> (8 * k)) & 0xffu), sx, h.x);
+            const float pny = fmaf_((float)((eny >> (8 * k)) & 0xffu), sy, h.y), pfy = fmaf_((float)((exy >> (8 * k)) & 0xffu), sy, h.y);
+            const float pnz = fmaf_((float)((enz >> (8 * k)) & 0xffu), sz, h.z), pfz = fmaf_((float)((exz >> (8 * k)) & 0xffu), sz, h.z);
+            const float tn = fmaxf(fmaxf(fmaf_(pnx, inv.x, cn.x), fmaf_(pny, inv.y, cn.y)), fmaf_(pnz, inv.z, cn.z));
+            const float tf = fminf(fminf(fmaf_(pfx, inv.x, cf.x), fmaf_(pfy, inv.y, cf.y)), fmaf_(pfz, inv.z, cf.z)) * kWiden;
+            // (no test for "no child": its box is inverted and its reference a harmless leaf -- pt_wide.cpp; a "hit" at
+            // tn = +inf is a ray parallel to a slab it is outside of: sorting it among the misses drops it, rightly)
+            const bool hit = (tf >= tn) && (tf >= 0.0f) && (tn <= lim);
+            key[k] = hit ? tn : __builtin_inff();
+            n += key[k] < __builtin_inff() ? 1 : 0;
+        }
+#define PT_CSWAP(a, b)                                                                        \
+        {                                                                                     \
+            const bool sw = key[a] > key[b];                                                  \
+            const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];                 \
+            const int ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];                   \
+            key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb;                               \
+        }
+        PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+        // the nearest child is a leaf and no leaf is pending: remember it (round() intersects it after the node phase)
+        // and go on with the next child -- fewer node-phase / leaf-phase alternations, as in node_step
+        const bool cap = n > 0 && is_leaf(ref[0]) && pend == 0;
+        pend = cap ? ref[0] : pend;
+        ref[0] = cap ? ref[1] : ref[0];
+        ref[1] = cap ? ref[2] : ref[1];
+        ref[2] = cap ? ref[3] : ref[2];
+        n -= cap ? 1 : 0;
+        // child j (1 <= j < n) goes to entry top + (n - j): popped nearest first; a missed child (j >= n) to top + j
+        char* const a1 = tos + (1 < n ? n - 1 : 1) * stride;
+        char* const a2 = tos + (2 < n ? n - 2 : 2) * stride;
+        char* const a3 = tos + (3 < n ? n - 3 : 3) * stride;
+        if (!tight) {
+            *reinterpret_cast<StackT*>(a1) = (StackT)ref[1];
+            *reinterpret_cast<StackT*>(a2) = (StackT)ref[2];
+            *reinterpret_cast<StackT*>(a3) = (StackT)ref[3];
+        } else {
+            stack_put(sv, a1, ref[1]);
+            stack_put(sv, a2, ref[2]);
+            stack_put(sv, a3, ref[3]);
+        }
+        cur = n > 0 ? ref[0] : top;
+        tos += (n > 0 ? n - 1 : -1) * stride;
+    }
+
     // exact test of packed triangle ti against the ray, keeping the closest (ties: lower rank)
     template <bool COUNT>
     PT_DEV void tri_step(const SceneView& sv, int ti, WorkCount* wc) {
@@ -521,6 +618,8 @@ struct Trav {
             while (is_node(cur)) node_step<COUNT, false, kVisitLds>(sv, wc);
         } else if (MODE == kNodesGlobal) {
             while (is_node(cur)) node_step<COUNT, true, kVisitGlobal>(sv, wc);
+        } else if (MODE == kNodesWide) {
+            while (is_node(cur)) wide_step<COUNT>(sv, wc);
         } else {
             while (is_node(cur)) node_step<COUNT, true, kVisitFlat>(sv, wc);
         }
@@ -531,7 +630,7 @@ struct Trav {
             pend = 0;
         }
         while (is_leaf(cur)) {
-            const int popped = (int)*reinterpret_cast<const StackT*>(tos);     // in flight during the triangle tests
+            const int popped = stack_get(sv, tos);     // in flight during the triangle tests
             const int v = leaf_bits(cur);
             const int first = v >> 3, count = (v & 7) + 1;
             for (int j = 0; j < count; ++j) tri_step<COUNT>(sv, first + j, wc);
@@ -740,6 +839,9 @@ PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<type
     sv->treelet = (unsigned)p.treelet_nodes;
     sv->n_flat = p.n_flat;
     sv->lds_nodes = nullptr;
+    sv->stk_end = reinterpret_cast<const char*>(stk->base) + (size_t)p.stack_entries * BLOCK * sizeof(typename StackOf<MODE>::type);
+    sv->ovf = p.stack_ovf ? p.stack_ovf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x) : nullptr;
+    sv->ovf_stride = (unsigned)p.stack_ovf_lanes;
     float4* lds_flat = reinterpret_cast<float4*>(pt_lds_raw + traversal_nodes_end_dev<MODE, BLOCK>(p));
     for (int i = threadIdx.x; i < p.n_flat * 3; i += BLOCK) lds_flat[i] = p.tris[i];
     sv->lds_flat = lds_flat;
@@ -760,7 +862,7 @@ PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<type
         rec[2] = make_float4(loz - pad, hiz + pad, hiz + pad, loz - pad);
     }
     sv->lds_fbox = reinterpret_cast<const char*>(lds_fbox);
-    if (MODE != kNodesGlobal) {
+    if (MODE == kNodesLds || MODE == kNodesTreelet) {
         float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + traversal_stack_bytes_dev<MODE, BLOCK>(p));
         stage_nodes<MODE>(p, lds_nodes);
         sv->lds_nodes = lds_nodes;

@@ -60,6 +60,8 @@ struct pt_context {
 
     // ---- packed scene (host copies kept for the debug getters)
     std::vector<Node64> nodes;
+    std::vector<Node4q> nodes4;   // the same tree collapsed to 4-wide quantised nodes (empty: not built), pt_wide.cpp
+    int wide_pending = 0;         // most entries a wide traversal can have pushed when it visits an interior node
     std::vector<TriPacket> packets;
     std::vector<TriMeta> meta;
     std::vector<int32_t> orig;
@@ -69,6 +71,9 @@ struct pt_context {
 
     // ---- device buffers
     float4* d_nodes = nullptr;
+    float4* d_nodes4 = nullptr;
+    uint32_t* d_stack_ovf = nullptr;   // kNodesWide: stack entries past the LDS part, [entry][lane of the grid]
+    size_t stack_ovf_lanes = 0;
     float4* d_tris = nullptr;
     TriMeta* d_meta = nullptr;
     pt_material* d_mats = nullptr;
@@ -108,6 +113,8 @@ struct pt_context {
     int flat_list = 16;        // at most this many big triangles go to the flat list (option flat_list; 0: none)
     int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
     int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 16 with the whole tree in LDS, else 24)
+    int wide_nodes = 1;    // 4-wide quantised nodes: 0 never, 1 for trees that do not fit LDS, 2 for every tree (tests)
+    int wide_lds_entries = kWideLdsEntries;   // 4-wide traversal: stack entries per lane kept in LDS (tests lower it to force the global part)
     int waves_per_simd = -1; // nodes from global memory: register budget for 4 / 5 / 6 waves per SIMD (-1: the most the LDS stacks allow)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
@@ -537,6 +544,9 @@ int deepest_interior_node(const std::vector<Node64>& nodes) {
     }
     return deepest;
 }
+// 4-wide nodes: a visit finds at most `pending` entries above the sentinel and stores its three other children above
+// the top, kept or not (Trav::wide_step)
+int wide_stack_entries(int pending) { return ((pending + 4) + 1) & ~1; }
 int stack_entries_for(int interior_depth) { return std::min(kStackEntries, ((interior_depth + 2) + 1) & ~1); }
 
 constexpr size_t kLdsPerCu = 160 * 1024;
@@ -601,8 +611,15 @@ int plan_node_placement(pt_context* ctx) {
     ctx->treelet_nodes = 0;
     ctx->interior_depth = deepest_interior_node(ctx->nodes);
     if (ctx->interior_depth + 2 > kStackEntries) return fail(ctx, PT_ESCENE, "internal: BVH deeper than the traversal stack");
-    if (ctx->treelet == 0 || whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->interior_depth)) return PT_OK;
-    ctx->treelet_nodes = reindex_treelet(ctx->nodes, ctx->interior_depth, ctx->treelet);
+    const bool fits = whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->interior_depth);
+    if (ctx->treelet != 0 && !fits) ctx->treelet_nodes = reindex_treelet(ctx->nodes, ctx->interior_depth, ctx->treelet);
+    // 4-wide nodes for trees read from global memory -- unless their worst-case stack would not leave room for four
+    // 256-thread workgroups per CU (then the BVH2 path stays)
+    ctx->nodes4.clear();
+    ctx->wide_pending = 0;
+    if (ctx->wide_nodes == 2 || (ctx->wide_nodes == 1 && !fits && ctx->treelet_nodes == 0)) {
+        if (!build_wide_nodes(ctx->nodes, &ctx->nodes4, &ctx->wide_pending)) ctx->nodes4.clear();
+    }
     return PT_OK;
 }
 
@@ -614,6 +631,21 @@ int upload_vec(pt_context* ctx, T** dptr, const void* src, size_t bytes) {
     // hit, so a leaf reference into an empty scene (the wrapped root's ~0) stays harmless
     if (bytes < 64) PT_HIP(ctx, hipMemset(*dptr, 0, 64));
     if (bytes) PT_HIP(ctx, hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+// kNodesWide: room for the stack entries past the LDS part, for every lane of the largest grid a traversal kernel of
+// this context is launched with (256-thread workgroups: persistent <= 6 per CU, wf_intersect 2 x 8 per CU, the debug
+// kernel 8 per CU, a non-persistent render one wave per tile)
+int alloc_stack_overflow(pt_context* ctx) {
+    if (ctx->d_stack_ovf) { PT_HIP(ctx, hipFree(ctx->d_stack_ovf)); ctx->d_stack_ovf = nullptr; }
+    ctx->stack_ovf_lanes = 0;
+    const int extra = ctx->nodes4.empty() ? 0 : wide_stack_entries(ctx->wide_pending) - ctx->wide_lds_entries;
+    if (extra <= 0) return PT_OK;
+    const size_t n_tiles = (size_t)((ctx->W + 7) / 8) * (size_t)((ctx->local_rows + 7) / 8);
+    const size_t lanes = 256 * std::max<size_t>((size_t)ctx->cu_count * 16, (n_tiles + 3) / 4);
+    PT_HIP(ctx, hipMalloc((void**)&ctx->d_stack_ovf, lanes * (size_t)extra * sizeof(uint32_t)));
+    ctx->stack_ovf_lanes = lanes;
     return PT_OK;
 }
 
@@ -649,6 +681,8 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->n_tris = (int32_t)ctx->orig.size();
     p->n_flat = ctx->n_flat;
     p->stack_entries = stack_entries_for(ctx->interior_depth);
+    p->stack_ovf = nullptr;
+    p->stack_ovf_lanes = 0;
     // where the traversal reads nodes from: the whole tree staged in LDS, its re-indexed top, or L1/L2 only
     p->node_mode = kNodesGlobal;
     p->treelet_nodes = 0;
@@ -659,6 +693,14 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
             p->node_mode = kNodesTreelet;
             p->treelet_nodes = ctx->treelet_nodes;
         }
+    }
+    if (!ctx->nodes4.empty() && (p->node_mode == kNodesGlobal || ctx->wide_nodes == 2)) {
+        p->node_mode = kNodesWide;
+        p->treelet_nodes = 0;
+        p->nodes = ctx->d_nodes4;
+        p->stack_entries = std::min(ctx->wide_lds_entries, wide_stack_entries(ctx->wide_pending));
+        p->stack_ovf = ctx->d_stack_ovf;
+        p->stack_ovf_lanes = (int32_t)ctx->stack_ovf_lanes;
     }
     p->tile_counter = nullptr;
     p->chunk_spp = 0;
@@ -856,6 +898,8 @@ void pt_destroy(pt_context* ctx) {
         (void)hipDeviceSynchronize();
         for (auto& e : ctx->events) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
         if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
+        if (ctx->d_nodes4) (void)hipFree(ctx->d_nodes4);
+        if (ctx->d_stack_ovf) (void)hipFree(ctx->d_stack_ovf);
         if (ctx->d_tris) (void)hipFree(ctx->d_tris);
         if (ctx->d_meta) (void)hipFree(ctx->d_meta);
         if (ctx->d_mats) (void)hipFree(ctx->d_mats);
@@ -1005,6 +1049,8 @@ static int build_on_device(pt_context* ctx, bool* done) {
         ctx->d_meta = r.d_meta;
         if (ctx->treelet_nodes > 0) PT_HIP(ctx, hipMemcpy(ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size(), hipMemcpyHostToDevice));
     }
+    if ((rc = upload_vec(ctx, &ctx->d_nodes4, ctx->nodes4.data(), sizeof(Node4q) * ctx->nodes4.size())) != PT_OK) return rc;
+    if ((rc = alloc_stack_overflow(ctx)) != PT_OK) return rc;
     *done = true;
     return PT_OK;
 }
@@ -1036,6 +1082,8 @@ int pt_upload_triangles(pt_context* ctx) {
     if (ctx->has_device) {
         PT_HIP(ctx, hipSetDevice(ctx->device));
         if ((rc = upload_vec(ctx, &ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size())) != PT_OK) return rc;
+        if ((rc = upload_vec(ctx, &ctx->d_nodes4, ctx->nodes4.data(), sizeof(Node4q) * ctx->nodes4.size())) != PT_OK) return rc;
+        if ((rc = alloc_stack_overflow(ctx)) != PT_OK) return rc;
         if ((rc = upload_vec(ctx, &ctx->d_tris, ctx->packets.data(), sizeof(TriPacket) * ctx->packets.size())) != PT_OK) return rc;
         if ((rc = upload_vec(ctx, &ctx->d_meta, ctx->meta.data(), sizeof(TriMeta) * ctx->meta.size())) != PT_OK) return rc;
     }
@@ -1094,7 +1142,7 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
     // resident workgroups at 4 waves per SIMD: 2 x 512 threads (whole tree in LDS), 1 x 1024 (treelet) per CU; nodes through
     // L1/L2 (256 threads): as many waves per SIMD -- 6, 5 or 4 -- as the stacks in LDS leave room for
     lc->waves_per_simd = 4;
-    if (p.node_mode == kNodesGlobal) {
+    if (p.node_mode == kNodesGlobal || p.node_mode == kNodesWide) {
         const int want = ctx->waves_per_simd > 0 ? ctx->waves_per_simd : 6;
         for (int w = std::min(want, 6); w > 4; --w)
             if ((size_t)w * lc->lds_bytes + 1024 <= kLdsPerCu) { lc->waves_per_simd = w; break; }
@@ -1213,7 +1261,7 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         const int resident_waves = ptamd_resident_waves(ctx, lc);
         // fewer tiles per resident wave (1080p over 2 / 4 / 8 GPUs: 4.0 / 2.0 / 1.0): suspend with passes of 16, lockstep with
         // passes of 8, lockstep with whole tiles (profiles/r02/q_*: 95.7 % / 87.5 % / 61.8 % of the one-GPU rate per GPU)
-        const int auto_chunk = p.n_tiles >= 6 * resident_waves ? (nsamples >= 256 ? 64 : 32)
+        const int auto_chunk = p.n_tiles >= 5 * resident_waves ? (nsamples >= 256 ? 64 : 32)
                              : p.n_tiles >= 3 * resident_waves ? 16
                              : p.n_tiles > resident_waves + resident_waves / 2 ? 8 : 0;
         const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk;
@@ -1419,6 +1467,14 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < -1 || value > 2048) return fail(ctx, PT_EINVAL, "treelet: 0 off, -1 as many nodes as fit, 2..2048 nodes");
         ctx->treelet = (int)value;
         ctx->tris_uploaded = false;                  // the tree is re-indexed at upload
+    } else if (k == "wide_nodes") {
+        if (value < 0 || value > 2) return fail(ctx, PT_EINVAL, "wide_nodes: 0 never, 1 for trees that do not fit LDS, 2 always");
+        ctx->wide_nodes = (int)value;
+        ctx->tris_uploaded = false;                  // the wide nodes are built at upload
+    } else if (k == "wide_lds_entries") {
+        if (value < 4 || value > kWideLdsEntries || (value & 1)) return fail(ctx, PT_EINVAL, "wide_lds_entries: even, 4..24");
+        ctx->wide_lds_entries = (int)value;
+        ctx->tris_uploaded = false;                  // the global part of the stacks is sized at upload
     } else if (k == "timing") {
         ctx->timing = value ? 1 : 0;
     } else if (k == "count_work") {
@@ -1481,6 +1537,8 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out) {
     if (k == "lds_bytes") { *out = (double)ctx->last_lds_bytes; return PT_OK; }
     if (k == "waves_per_simd") { *out = (double)ctx->last_waves_per_simd; return PT_OK; }
     if (k == "treelet_nodes") { *out = (double)ctx->treelet_nodes; return PT_OK; }
+    if (k == "wide_nodes") { *out = (double)ctx->nodes4.size(); return PT_OK; }
+    if (k == "wide_pending") { *out = (double)ctx->wide_pending; return PT_OK; }
     if (k == "flat_triangles") { *out = (double)ctx->n_flat; return PT_OK; }
     if (k == "node_mode") {      // what the next launch will use: 0 whole tree in LDS, 1 L1/L2 only, 2 treelet
         pt_camera cam;
@@ -1517,6 +1575,13 @@ int pt_debug_bvh_sizes(const pt_context* ctx, int64_t* nnodes, int64_t* ntris) {
     if (!ctx) return PT_EINVAL;
     if (nnodes) *nnodes = (int64_t)ctx->nodes.size();
     if (ntris) *ntris = (int64_t)ctx->orig.size();
+    return PT_OK;
+}
+
+int pt_debug_wide_nodes(const pt_context* ctx, void* out, int64_t capacity, int64_t* count) {
+    if (!ctx || !count || capacity < 0) return PT_EINVAL;
+    *count = (int64_t)ctx->nodes4.size();
+    if (out) std::memcpy(out, ctx->nodes4.data(), sizeof(Node4q) * (size_t)std::min<int64_t>(capacity, *count));
     return PT_OK;
 }
 

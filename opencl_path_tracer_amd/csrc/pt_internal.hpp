@@ -38,8 +38,26 @@ struct TriMeta {
     int32_t mati;
 };
 
+// 4-wide node, 64 B = 4 x float4 (pt_wide.cpp builds it from the BVH2; Trav<kNodesWide>::wide_step reads it):
+//   { origin.xyz, exp_x | exp_y << 8 | exp_z << 16 | nchild << 24 }      grid of the node: plane = origin + q * 2^(exp - 127)
+//   { qlo_x, qhi_x, qlo_y, qhi_y }   { qlo_z, qhi_z, -, - }              byte k of each word = child k's plane on that grid
+//   { ref[0..3] }                    child references as in Node64; kWideNoChild (and an inverted box) where there is no child
+struct Node4q {
+    float origin[3];
+    uint8_t exp[3];
+    uint8_t nchild;
+    uint32_t qlo_x, qhi_x, qlo_y, qhi_y;
+    uint32_t qlo_z, qhi_z;
+    uint32_t spare[2];
+    int32_t ref[4];
+};
+static_assert(sizeof(Node4q) == 64, "Node4q must be 64 B");
+constexpr int32_t kWideNoChild = ~0;      // the leaf {packet 0, 1 triangle}: always present (an empty scene holds one all-zero packet)
+constexpr int kWideLdsEntries = 24;   // 24 x 4 B x 256 lanes = 24 KB per workgroup: six workgroups per CU next to the big-triangle list
+bool build_wide_nodes(const std::vector<Node64>& bvh2, std::vector<Node4q>* out, int* max_pending);   // pt_wide.cpp
+
 // Where the traversal reads BVH nodes from (Trav<MODE> in pt_device.hpp)
-enum : int { kNodesLds = 0, kNodesGlobal = 1, kNodesTreelet = 2 };
+enum : int { kNodesLds = 0, kNodesGlobal = 1, kNodesTreelet = 2, kNodesWide = 3 };
 
 // Packets and nodes are addressed with 32-bit byte offsets on the device (index * 48, index << 6) and a
 // leaf reference holds first << 3 in 31 bits: 2^26 triangles (hence < 2^26 nodes) keep all three in range.
@@ -69,9 +87,12 @@ struct RenderParams {
     int32_t iterations, first_sample, nsamples;
     int32_t n_nodes, n_tris;
     int32_t n_flat;              // packets [0, n_flat) are the big-triangle list: tested by every ray before the tree
-    int32_t node_mode;           // kNodesLds / kNodesGlobal / kNodesTreelet: where the traversal reads BVH nodes from
+    int32_t node_mode;           // kNodesLds / kNodesGlobal / kNodesTreelet / kNodesWide: where the traversal reads BVH nodes from (and which)
     int32_t treelet_nodes;       // kNodesTreelet: nodes [0, treelet_nodes) are staged in LDS
-    int32_t stack_entries;       // per-lane stack depth actually needed (sentinel + BVH depth + the slot above the top)
+    int32_t stack_entries;       // per-lane stack entries in LDS: all a BVH2 traversal can need (sentinel + deepest interior node + the slot
+                                 // above the top); kNodesWide: at most kWideLdsEntries, the rest of the worst case in stack_ovf
+    uint32_t* stack_ovf;         // kNodesWide: [entries past the LDS part][lane of the grid], or null when LDS holds the worst case
+    int32_t stack_ovf_lanes;     // lanes stack_ovf has room for (every launch's grid must fit)
     uint32_t* tile_counter;      // != 0: persistent launch, waves pull tile indices from this counter
     int32_t n_tiles;
     int32_t chunk_spp;           // > 0: a work item is (pass, tile) = chunk_spp samples of a tile; passes of one

@@ -381,6 +381,7 @@ static hipError_t launch_one(const RenderParams& p, const LaunchConfig& lc, hipS
     constexpr int wpb = BLOCK / 64;
     int blocks = (waves + wpb - 1) / wpb;
     if (p.tile_counter) blocks = std::min(blocks, lc.persistent_blocks);
+    if (p.stack_ovf && (long long)blocks * BLOCK > (long long)p.stack_ovf_lanes) return hipErrorInvalidValue;   // (pt_host.cpp alloc_stack_overflow)
     auto kern = k_render<SPLIT, MODE, BLOCK, COUNT, SCHED, WPS>;
     if (lc.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc.lds_bytes);
@@ -399,6 +400,10 @@ static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc,
         if (lc.waves_per_simd == 6) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 6>(p, lc, stream);
         if (lc.waves_per_simd == 5) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 5>(p, lc, stream);
         return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 4>(p, lc, stream);
+    case kNodesWide:
+        if (lc.waves_per_simd == 6) return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 6>(p, lc, stream);
+        if (lc.waves_per_simd == 5) return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 5>(p, lc, stream);
+        return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 4>(p, lc, stream);
     case kNodesTreelet: return launch_one<SPLIT, kNodesTreelet, 1024, COUNT, SCHED, 4>(p, lc, stream);
     }
     return hipErrorInvalidValue;

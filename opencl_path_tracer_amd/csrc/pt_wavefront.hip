@@ -326,6 +326,7 @@ static hipError_t launch_wf_intersect_t(const WfParams& w, int bounce, int resid
         if (e != hipSuccess) return e;
     }
     const int blocks = std::min((w.npix + RPB - 1) / RPB, resident_blocks);
+    if (w.rp.stack_ovf && 2ll * blocks * BLOCK > (long long)w.rp.stack_ovf_lanes) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(blocks, 2), dim3(BLOCK), lds, stream, w, bounce);
     return hipGetLastError();
 }
@@ -335,6 +336,7 @@ hipError_t launch_wf_intersect(const WfParams& w, int bounce, int cu_count, hipS
     switch (w.rp.node_mode) {
     case kNodesLds: return launch_wf_intersect_t<kNodesLds, 512>(w, bounce, cu_count * 2, stream);
     case kNodesGlobal: return launch_wf_intersect_t<kNodesGlobal, 256>(w, bounce, cu_count * 8, stream);
+    case kNodesWide: return launch_wf_intersect_t<kNodesWide, 256>(w, bounce, cu_count * 8, stream);
     case kNodesTreelet: return launch_wf_intersect_t<kNodesTreelet, 1024>(w, bounce, cu_count, stream);
     }
     return hipErrorInvalidValue;

@@ -82,28 +82,30 @@ def test_split_api_equals_fused(api, oracle, cb_spec, cb_oracle_scene):
     assert same_bits(r2["D"][:, :3], fr2.rays()["D"][:, :3]) and np.array_equal(c.read_rnds(), fr2.rnds())
 
 
-@pytest.mark.parametrize("lds", [2, 0])
-def test_node_paths_identical(api, oracle, cb_spec, cb_oracle_scene, lds):
-    """Whole tree staged in LDS (default) and every node through L1/L2: same frame."""
+@pytest.mark.parametrize("lds,wide,mode", [(2, 1, 0), (0, 1, 1), (2, 2, 3)])
+def test_node_paths_identical(api, oracle, cb_spec, cb_oracle_scene, lds, wide, mode):
+    """Whole tree staged in LDS (default), every node through L1/L2, 4-wide quantised nodes: same frame."""
     W, H = 96, 72
-    sc = api.Scene(W, H).load(cb_spec)
+    sc = api.Scene(W, H)
+    sc.set_option("wide_nodes", wide)
+    sc.load(cb_spec)
     sc.set_option("lds_scene", lds)
-    assert sc.stat("node_mode") == (0 if lds else 1)
+    assert sc.stat("node_mode") == mode
     sc.iterations = 8
     sc.render(2)
     sc.render(2)                                   # continues from current_sample = 2
     fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 8, 4)
-    check(sc, fr, "lds_scene=%d" % lds)
-    assert (sc.stat("lds_bytes") > 60 * 1024) == (lds == 2)
+    check(sc, fr, "lds_scene=%d wide_nodes=%d" % (lds, wide))
+    assert (sc.stat("lds_bytes") > 60 * 1024) == (mode == 0)
 
 
-@pytest.mark.parametrize("lds_scene", [2, 0])
+@pytest.mark.parametrize("lds_scene,wide", [(2, 1), (0, 1), (2, 2)])
 @pytest.mark.parametrize("ntris", [0, 1, 2, 5])
-def test_tiny_and_empty_scenes(api, oracle, ntris, lds_scene):
+def test_tiny_and_empty_scenes(api, oracle, ntris, lds_scene, wide):
     """Scenes below the leaf size: the BVH is a wrapped root with one or two (empty) leaf children.
     0 triangles: every path misses, the frame stays black and each sample draws exactly its two
     camera-jitter values; 1..5 triangles (an emitter quad, a floor, a tilted mirror): same frame as
-    the oracle on both node paths."""
+    the oracle on the node paths (the 4-wide root then has no child, or one)."""
     from opencl_path_tracer_amd import scenes
     mats = list(scenes.BUILTIN_MATERIALS)
     quad = np.array([[[200, 999, -200], [800, 999, -200], [800, 999, 400]], [[200, 999, -200], [800, 999, 400], [200, 999, 400]],
@@ -116,6 +118,7 @@ def test_tiny_and_empty_scenes(api, oracle, ntris, lds_scene):
     W, H = 40, 24
     sc = api.Scene(W, H)
     sc.set_option("lds_scene", lds_scene)
+    sc.set_option("wide_nodes", wide)
     for m in mats:
         sc.add_Material(*m)
     if ntris:
@@ -143,7 +146,7 @@ def test_tiny_and_empty_scenes(api, oracle, ntris, lds_scene):
     cam = oracle.make_camera(60, 0, 0, (0, 0, 0), W, H)
     fr = oracle.OracleFrame(W, H)
     segs = fr.render(osc, cam, 6, 0, 3, mode=2, nthreads=8)
-    check(sc, fr, "%d triangles, lds_scene %d" % (ntris, lds_scene))
+    check(sc, fr, "%d triangles, lds_scene %d, wide_nodes %d" % (ntris, lds_scene, wide))
     assert sc.stat("segments") == segs
 
 
@@ -178,12 +181,13 @@ def test_tiled_ranks_union_equals_single(api, oracle, cb_spec, cb_oracle_scene):
 
 
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("lds,treelet", [(2, -1), (2, 40), (0, -1), (2, 0)])
-def test_mesh_scene_treelet_and_global_paths(api, oracle, lds, treelet, variant):
+@pytest.mark.parametrize("lds,treelet,wide,mode", [(2, -1, 1, 2), (2, 40, 1, 2), (0, -1, 1, 1), (2, 0, 0, 1), (2, 0, 1, 3), (2, 0, 2, 3)])
+def test_mesh_scene_treelet_and_global_paths(api, oracle, lds, treelet, wide, mode, variant):
     """A scene too large for whole-tree staging (displaced grid, ~6k triangles, ~3k nodes, all four
     material types reachable): the top of the tree is staged in LDS (treelet: automatic size, or only 40
-    nodes so that most visits cross between the two node paths) or every node is read through L1/L2;
-    megakernel and wavefront; parity bar unchanged."""
+    nodes so that most visits cross between the two node paths) or every node is read through L1/L2, as BVH2 nodes
+    or collapsed to 4-wide quantised ones (the default without a treelet; with only 6 of the lanes' stack entries in
+    LDS, so that the part in global memory is in use); megakernel and wavefront; parity bar unchanged."""
     from opencl_path_tracer_amd import scenes
     spec = scenes.displaced_grid_mesh(6000)
     osc = oracle.load_scene(spec)
@@ -192,14 +196,17 @@ def test_mesh_scene_treelet_and_global_paths(api, oracle, lds, treelet, variant)
     sc.set_option("treelet", treelet)
     sc.set_option("lds_scene", lds)
     sc.set_option("variant", variant)
+    sc.set_option("wide_nodes", wide)
+    if wide == 2:
+        sc.set_option("wide_lds_entries", 6)
     sc.load(spec)
-    assert sc.stat("node_mode") == (2 if lds and treelet else 1)
+    assert sc.stat("node_mode") == mode
     if lds and treelet == 40:
         assert sc.stat("treelet_nodes") == 40
     sc.iterations = 6
     sc.render(3)
     fr, _ = oracle_render(oracle, osc, spec, W, H, 6, 3)
-    check(sc, fr, "mesh lds=%d treelet=%d variant=%d" % (lds, treelet, variant))
+    check(sc, fr, "mesh lds=%d treelet=%d wide=%d variant=%d" % (lds, treelet, wide, variant))
 
 
 def test_oracle_modes_agree_with_gpu_on_exhaustive_search(api, oracle, cb_spec, cb_oracle_scene):
@@ -427,23 +434,25 @@ def test_wavefront_tiled_and_mesh(api, oracle, cb_spec, cb_oracle_scene):
     check(sc, fr2, "wavefront mesh")
 
 
-@pytest.mark.parametrize("ntris,W,H,bounces,spp,variant,lds", [(100000, 96, 64, 8, 2, 0, 2), (100000, 96, 64, 8, 2, 0, 0), (100000, 64, 48, 8, 2, 1, 2),
-                                                                 (1000000, 48, 48, 16, 2, 0, 2), (1000000, 48, 48, 16, 2, 0, 0), (1000000, 48, 48, 16, 2, 1, 2)])
-def test_mesh_configs_c3_c5(api, oracle, ntris, W, H, bounces, spp, variant, lds):
+@pytest.mark.parametrize("ntris,W,H,bounces,spp,variant,lds,wide", [
+    (100000, 96, 64, 8, 2, 0, 2, 1), (100000, 96, 64, 8, 2, 0, 0, 1), (100000, 96, 64, 8, 2, 0, 0, 0), (100000, 64, 48, 8, 2, 1, 2, 1), (100000, 64, 48, 8, 2, 1, 0, 1),
+    (1000000, 48, 48, 16, 2, 0, 2, 1), (1000000, 48, 48, 16, 2, 0, 0, 1), (1000000, 48, 48, 16, 2, 0, 0, 0), (1000000, 48, 48, 16, 2, 1, 2, 1), (1000000, 48, 48, 16, 2, 1, 0, 1)])
+def test_mesh_configs_c3_c5(api, oracle, ntris, W, H, bounces, spp, variant, lds, wide):
     """BASELINE configs 3 and 5 (MESH-100k at 8 bounces, MESH-1M at 16 bounces: SURVEY 8d synthetic
     displaced-grid meshes inside the Cornell walls) at frame sizes the oracle finishes in seconds."""
     from opencl_path_tracer_amd import scenes
     spec = scenes.displaced_grid_mesh(ntris)
     osc = oracle.load_scene(spec)
     sc = api.Scene(W, H)
-    sc.set_option("treelet", -1 if lds else 0)     # lds 2: the top of the tree staged in LDS; 0 (the default): L1/L2 only
+    sc.set_option("treelet", -1 if lds else 0)     # lds 2: the top of the tree staged in LDS; 0 (the default): L1/L2 only,
+    sc.set_option("wide_nodes", wide)              # as 4-wide quantised nodes (the default) or as the BVH2
     sc.load(spec)
     sc.set_option("variant", variant)
-    assert sc.stat("node_mode") == (2 if lds else 1) and (sc.stat("treelet_nodes") > 500) == (lds == 2)
+    assert sc.stat("node_mode") == (2 if lds else 3 if wide else 1) and (sc.stat("treelet_nodes") > 500) == (lds == 2)
     sc.iterations = bounces
     sc.render(spp)
     fr, segs = oracle_render(oracle, osc, spec, W, H, bounces, spp)
-    check(sc, fr, "mesh %d lds_scene %d" % (ntris, lds))
+    check(sc, fr, "mesh %d lds_scene %d wide_nodes %d" % (ntris, lds, wide))
     assert sc.stat("segments") == segs
 
 
@@ -556,11 +565,11 @@ def test_closest_hit_unit_level(api, oracle, cb_spec, cb_oracle_scene):
     assert np.array_equal(tris_add_order["mati"][tri[hitmask]], h2["mati"][hitmask])
 
 
-@pytest.mark.parametrize("lds_scene", [2, 0])
-def test_closest_hit_adversarial_rays(api, oracle, cb_spec, cb_oracle_scene, lds_scene):
-    """Rays chosen against the conservative slab tests of both node paths (nodes staged in LDS:
+@pytest.mark.parametrize("lds_scene,wide", [(2, 1), (0, 1), (2, 2)])
+def test_closest_hit_adversarial_rays(api, oracle, cb_spec, cb_oracle_scene, lds_scene, wide):
+    """Rays chosen against the conservative slab tests of the node paths (nodes staged in LDS:
     address-selected planes + one fma per plane with widened constants; nodes from global memory:
-    (plane - P) * inv): origins 1e4..1e7 away from the scene (|P * inv| >> t, where the fma form
+    sign-selected planes, the same fma; 4-wide nodes: planes decoded from bytes first): origins 1e4..1e7 away from the scene (|P * inv| >> t, where the fma form
     cancels), direction components that are tiny, denormal or exactly +-0, origins exactly on the
     wall planes and sliding along them, origins inside the spheres.  The device result must be
     bit-identical to the oracle's exhaustive search on every ray."""
@@ -593,7 +602,9 @@ def test_closest_hit_adversarial_rays(api, oracle, cb_spec, cb_oracle_scene, lds
     rays["D"][:, :3] = D
     sc = api.Scene(16, 16)
     sc.set_option("lds_scene", lds_scene)
+    sc.set_option("wide_nodes", wide)
     sc.load(cb_spec)
+    assert sc.stat("node_mode") == (3 if wide == 2 else 0 if lds_scene else 1)
     t, tri = sc.debug_closest_hit(rays)
     h2 = cb_oracle_scene.closest_hit(rays.view(oracle.RAY), mode=2)
     ot2 = np.where(h2["t"] > 0, h2["t"], np.float32(-1))
@@ -655,15 +666,18 @@ def test_closest_hit_unit_level_mesh(api, oracle):
     ot0 = np.where(h0["t"] > 0, h0["t"], np.float32(-1))
     ot2 = np.where(h2["t"] > 0, h2["t"], np.float32(-1))
     assert same_bits(ot0, ot2)
-    for policy, lds, treelet in ((0, 2, -1), (0, 2, 64), (0, 2, 0), (4, 2, -1), (4, 2, 0)):
+    for policy, lds, treelet, wide in ((0, 2, -1, 1), (0, 2, 64, 1), (0, 2, 0, 1), (0, 2, 0, 0), (4, 2, -1, 1), (4, 2, 0, 1), (4, 2, 0, 0)):
         sc = api.Scene(16, 16)
         sc.set_option("bvh_policy", policy)
         sc.set_option("treelet", treelet)
         sc.set_option("lds_scene", lds)
+        sc.set_option("wide_nodes", wide)
+        if policy == 4:
+            sc.set_option("wide_lds_entries", 8)
         sc.load(spec)
-        assert sc.stat("node_mode") == (2 if treelet else 1)
+        assert sc.stat("node_mode") == (2 if treelet else 3 if wide else 1)
         t, tri = sc.debug_closest_hit(rays)
-        assert same_bits(t, ot2), "bvh_policy %d lds_scene %d treelet %d" % (policy, lds, treelet)
+        assert same_bits(t, ot2), "bvh_policy %d lds_scene %d treelet %d wide_nodes %d" % (policy, lds, treelet, wide)
         assert (tri >= 0).sum() > 2500
 
 
@@ -753,14 +767,18 @@ def test_schedules_identical(api, oracle, cb_spec, cb_oracle_scene, schedule, k)
             assert sc.stat("wave_trips") >= sc.stat("wave_shade_steps") > 0 and sc.stat("node_visits") > sc.stat("wave_node_steps") > 0
     spec = scenes.displaced_grid_mesh(6000)
     osc = oracle.load_scene(spec)
-    sc = api.Scene(64, 64).load(spec)
-    sc.set_option("schedule", schedule)
-    sc.set_option("suspend_lanes", k)
-    sc.iterations = 6
-    sc.render(3)
     fr2, segs2 = oracle_render(oracle, osc, spec, 64, 64, 6, 3)
-    check(sc, fr2, "schedule=%d suspend_lanes=%d treelet" % (schedule, k))
-    assert sc.stat("segments") == segs2
+    for wide, lds_entries in ((0, 24), (1, 24), (1, 4)):       # BVH2 through L1/L2; 4-wide nodes, stacks in LDS / mostly in global memory
+        sc = api.Scene(64, 64)
+        sc.set_option("wide_nodes", wide)
+        sc.set_option("wide_lds_entries", lds_entries)
+        sc.load(spec)
+        sc.set_option("schedule", schedule)
+        sc.set_option("suspend_lanes", k)
+        sc.iterations = 6
+        sc.render(3)
+        check(sc, fr2, "schedule=%d suspend_lanes=%d wide_nodes=%d lds entries %d" % (schedule, k, wide, lds_entries))
+        assert sc.stat("segments") == segs2
 
 
 def _mesh100k_from_obj(api, oracle, tmp_path, W, H, **ctx_kw):
@@ -800,7 +818,7 @@ def test_config3_mesh_through_add_obj(api, oracle, tmp_path):
     assert tris[12:].tobytes() == api.triangles_from_vertices(verts, mati).tobytes()
     for k, mi in enumerate((scenes.WHITE_DIFFUSE, scenes.CHROMIUM, scenes.GLASS)):
         assert mats[10 + k].tobytes() == api.Material(*scenes.BUILTIN_MATERIALS[mi])[0].tobytes()
-    assert sc.stat("node_mode") == 1                     # 50 k nodes: read through L1/L2
+    assert sc.stat("node_mode") == 3                     # 50 k nodes: read through L1/L2, as 23 k 4-wide nodes
     osc = oracle.OracleScene()
     for m in list(scenes.BUILTIN_MATERIALS) + [scenes.BUILTIN_MATERIALS[i] for i in (scenes.WHITE_DIFFUSE, scenes.CHROMIUM, scenes.GLASS)]:
         osc.add_Material(*m)

@@ -69,7 +69,11 @@ def test_treelet_reindexing(api, ntris, want):
     assert sc.stat("flat_triangles") == 12
     bvh_check.validate_structure(nodes, tris, spec.ntris, 12)
     if want == 0:             # the default
-        assert T == 0 and sc.stat("node_mode") == 1
+        assert T == 0 and sc.stat("node_mode") == 3          # no treelet: 4-wide nodes through L1/L2
+        sc2 = api.Scene(16, 16, device=None)
+        sc2.set_option("wide_nodes", 0)
+        sc2.load(spec)
+        assert sc2.stat("node_mode") == 1
         return
     assert sc.stat("node_mode") == 2
     entries = int(sc.stat("stack_entries"))
@@ -94,6 +98,27 @@ def test_treelet_reindexing(api, ntris, want):
     frontier = [i for i in range(T, nodes.shape[0]) if parent[i] < T]
     if frontier:
         assert area[frontier].max() <= area[:T].min()
+
+
+@pytest.mark.parametrize("which", ["cornell", "mesh6k", "mesh100k"])
+def test_wide_nodes_contain_the_bvh2(api, cb_spec, which):
+    """4-wide quantised nodes (pt_wide.cpp): same leaves as the BVH2, every decoded child box contains the BVH2 boxes
+    below it, and the reported stack bound is the one the structure implies."""
+    from opencl_path_tracer_amd import scenes
+    spec = cb_spec if which == "cornell" else scenes.displaced_grid_mesh(6000 if which == "mesh6k" else 100000)
+    sc = api.Scene(16, 16, device=None)
+    sc.set_option("wide_nodes", 2)
+    sc.load(spec)
+    nodes, tris, meta, orig = sc.debug_bvh()
+    wide = sc.debug_wide_nodes()
+    assert wide.shape[0] == sc.stat("wide_nodes") > 0 and sc.stat("node_mode") == 3
+    assert wide.shape[0] < 0.56 * nodes.shape[0]
+    pending = bvh_check.validate_wide(nodes, wide, spec.ntris, int(sc.stat("flat_triangles")))
+    assert pending == sc.stat("wide_pending")
+    # default: only trees that do not fit LDS are collapsed
+    sc2 = api.Scene(16, 16, device=None).load(spec)
+    assert (sc2.stat("wide_nodes") > 0) == (which != "cornell")
+    assert sc2.stat("node_mode") == (3 if which != "cornell" else 0)
 
 
 def test_flat_list_selection(api, cb_spec):
