@@ -222,7 +222,9 @@ struct SceneView {
     unsigned treelet;          // kNodesTreelet: node indices below this are read from lds_nodes
     int n_flat;                // packets [0, n_flat): big triangles kept out of the tree, tested first (flat_pass)
     const float4* lds_flat;    // their packets, staged in LDS
-    const char* lds_fbox;      // their padded boxes, 48 B each: per axis {lo, hi, hi, lo} (planes picked by address, like a staged node)
+    int n_fbox;                // their distinct padded boxes (the halves of a wall share one) ...
+    const char* lds_fbox;      // ... 48 B each: per axis {lo, hi, hi, lo} (planes picked by address, like a staged node)
+    const unsigned* lds_fmask; // ... and which listed triangles each one covers
     // kNodesWide: the lane's stack continues in global memory past its LDS entries (a 4-wide traversal can have three
     // children pending per level, far more than it usually has; LDS holds what keeps six waves per SIMD resident)
     const char* stk_end;       // the lane's first stack address past its LDS entries
@@ -580,10 +582,11 @@ struct Trav {
 
     // The big-triangle list (the host keeps walls, floors ... out of the tree: pt_host.cpp build_and_pack), tested
     // at the start of every traversal; what it finds prunes the tree from its first node visit.  Two passes:
-    //  1. every lane slab-tests the padded box of every listed triangle -- a wave-uniform loop at full lane
-    //     utilisation, 14 VALU + 3 broadcast-free LDS reads per box, planes picked by address from the direction
-    //     signs exactly as for a staged node -- and notes the boxes it touches in a bit mask (the same conservative
-    //     cull a leaf box performs in the tree);
+    //  1. every lane slab-tests the DISTINCT padded boxes of the listed triangles (the two halves of a wall share
+    //     one: 6 boxes for the Cornell box's 12 triangles, grouped by the host) -- a wave-uniform loop at full lane
+    //     utilisation, 14 VALU + 4 LDS reads per box, planes picked by address from the direction signs exactly as
+    //     for a staged node -- and notes the triangles of the boxes it touches in a bit mask (the same
+    //     conservative cull a leaf box performs in the tree);
     //  2. each lane runs the exact test only on ITS candidates (2-6 of the 12 in the Cornell box: a wall is two
     //     triangles with one box, and a ray may cross the planes of a few walls), packets read from the LDS copy
     //     at a per-lane address.
@@ -594,14 +597,14 @@ struct Trav {
         const float kWiden = 1.0000005f;
         unsigned mask = 0;
 #pragma clang loop unroll(disable) vectorize(disable)      // (unrolled x8 it spills 40 registers around the loop)
-        for (int i = 0; i < sv.n_flat; ++i) {
+        for (int i = 0; i < sv.n_fbox; ++i) {
             const char* bb = sv.lds_fbox + i * 48;
             const float2 x = *reinterpret_cast<const float2*>(bb + onx);      // (entry plane, exit plane) of the axis
             const float2 y = *reinterpret_cast<const float2*>(bb + ony);
             const float2 z = *reinterpret_cast<const float2*>(bb + onz);
             const float tn = fmaxf(fmaxf(fmaf_(x.x, inv.x, cn.x), fmaf_(y.x, inv.y, cn.y)), fmaf_(z.x, inv.z, cn.z));
             const float tf = fminf(fminf(fmaf_(x.y, inv.x, cf.x), fmaf_(y.y, inv.y, cf.y)), fmaf_(z.y, inv.z, cf.z)) * kWiden;
-            mask |= ((tf >= tn) && (tf >= 0.0f)) ? (1u << i) : 0u;
+            mask |= ((tf >= tn) && (tf >= 0.0f)) ? sv.lds_fmask[i] : 0u;
         }
 #pragma clang loop unroll(disable)
         while (mask != 0) {
@@ -826,7 +829,7 @@ PT_DEV size_t traversal_nodes_end_dev(const RenderParams& p) {
 }
 template <int MODE, int BLOCK>
 PT_DEV size_t traversal_lds_bytes_dev(const RenderParams& p) {      // == traversal_lds_bytes() on the host
-    return traversal_nodes_end_dev<MODE, BLOCK>(p) + (size_t)p.n_flat * 96;     // packets + boxes of the big-triangle list
+    return traversal_nodes_end_dev<MODE, BLOCK>(p) + (size_t)p.n_flat * 100;    // packets + boxes + box-group masks of the big-triangle list
 }
 template <int MODE, int BLOCK>
 PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<typename StackOf<MODE>::type>* stk) {
@@ -848,8 +851,11 @@ PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<type
     // padded boxes of the listed triangles (what padded_bounds() gives a triangle in a leaf: 1e-5 of the largest
     // coordinate + 1e-6), per axis {lo, hi, hi, lo} so that (entry, exit) is one 8-byte read at + 0 or + 8
     float* lds_fbox = reinterpret_cast<float*>(lds_flat + p.n_flat * 3);
-    for (int i = threadIdx.x; i < p.n_flat; i += BLOCK) {
-        const float4 a = p.tris[i * 3], b = p.tris[i * 3 + 1], c = p.tris[i * 3 + 2];
+    unsigned* lds_fmask = reinterpret_cast<unsigned*>(lds_fbox + p.n_flat * 12);
+    for (int i = threadIdx.x; i < p.n_fbox; i += BLOCK) {
+        const int t = p.fbox_rep[i];
+        lds_fmask[i] = p.fbox_mask[i];
+        const float4 a = p.tris[t * 3], b = p.tris[t * 3 + 1], c = p.tris[t * 3 + 2];
         const float lox = fminf(fminf(a.x, a.w), b.z), hix = fmaxf(fmaxf(a.x, a.w), b.z);
         const float loy = fminf(fminf(a.y, b.x), b.w), hiy = fmaxf(fmaxf(a.y, b.x), b.w);
         const float loz = fminf(fminf(a.z, b.y), c.x), hiz = fmaxf(fmaxf(a.z, b.y), c.x);
@@ -862,6 +868,8 @@ PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<type
         rec[2] = make_float4(loz - pad, hiz + pad, hiz + pad, loz - pad);
     }
     sv->lds_fbox = reinterpret_cast<const char*>(lds_fbox);
+    sv->lds_fmask = lds_fmask;
+    sv->n_fbox = p.n_fbox;
     if (MODE == kNodesLds || MODE == kNodesTreelet) {
         float4* lds_nodes = reinterpret_cast<float4*>(pt_lds_raw + traversal_stack_bytes_dev<MODE, BLOCK>(p));
         stage_nodes<MODE>(p, lds_nodes);

@@ -68,6 +68,9 @@ struct pt_context {
     int bvh_depth = 0;
     int interior_depth = 0;   // depth of the deepest interior node of the packed tree (root: 0): sizes the traversal stacks
     int n_flat = 0;             // packed triangles [0, n_flat): the big-triangle list tested before the tree
+    int n_fbox = 0;             // its distinct bounding boxes: representative packet and the listed triangles each one covers
+    uint8_t fbox_rep[32] = {};
+    uint32_t fbox_mask[32] = {};
 
     // ---- device buffers
     float4* d_nodes = nullptr;
@@ -552,12 +555,12 @@ int stack_entries_for(int interior_depth) { return std::min(kStackEntries, ((int
 constexpr size_t kLdsPerCu = 160 * 1024;
 // next to the stacks and the staged nodes: the big-triangle list (96 B each) and, in wf_intersect, one class byte per ray
 // of a trip (16 waves x 256) + the compaction counters
-constexpr size_t kLdsSlack = 32 * 96 + 4096 + 1024 + 256;
+constexpr size_t kLdsSlack = 32 * 100 + 4096 + 1024 + 256;
 
 // Does the whole tree fit next to two 512-thread workgroups per CU (kNodesLds: 16-bit references)?
 bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int interior_depth) {
     const bool s16 = n_nodes <= 32767 && n_tris <= 4096;
-    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(interior_depth) * 2 * 512 + 32 * 96 + 32 <= kLdsPerCu / 2;   // (+ flat list: packet + box per triangle)
+    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(interior_depth) * 2 * 512 + 32 * 100 + 32 <= kLdsPerCu / 2;   // (+ flat list: packet + box + group mask per triangle)
 }
 
 // Treelet: when the tree is too large for LDS, the T nodes with the largest boxes --
@@ -607,8 +610,34 @@ int reindex_treelet(std::vector<Node64>& nodes, int interior_depth, int want) {
     return t_final;
 }
 
+// The listed triangles whose bounding boxes coincide -- the two halves of an axis-aligned wall -- are culled with ONE
+// box test (Trav::flat_pass): group them by the vertex extremes the kernel pads into that box.
+static void group_flat_boxes(pt_context* ctx) {
+    ctx->n_fbox = 0;
+    float ext[32][6];
+    for (int k = 0; k < ctx->n_flat; ++k) {
+        const float* v = ctx->packets[(size_t)k].v;          // r1, r2, r3
+        float e[6];
+        for (int a = 0; a < 3; ++a) {
+            e[a] = std::min(std::min(v[a], v[3 + a]), v[6 + a]);
+            e[3 + a] = std::max(std::max(v[a], v[3 + a]), v[6 + a]);
+        }
+        int b = 0;
+        for (; b < ctx->n_fbox; ++b)
+            if (std::memcmp(ext[b], e, sizeof e) == 0) break;
+        if (b == ctx->n_fbox) {
+            std::memcpy(ext[b], e, sizeof e);
+            ctx->fbox_rep[b] = (uint8_t)k;
+            ctx->fbox_mask[b] = 0;
+            ctx->n_fbox++;
+        }
+        ctx->fbox_mask[b] |= 1u << k;
+    }
+}
+
 int plan_node_placement(pt_context* ctx) {
     ctx->treelet_nodes = 0;
+    group_flat_boxes(ctx);
     ctx->interior_depth = deepest_interior_node(ctx->nodes);
     if (ctx->interior_depth + 2 > kStackEntries) return fail(ctx, PT_ESCENE, "internal: BVH deeper than the traversal stack");
     const bool fits = whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->interior_depth);
@@ -680,6 +709,9 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->n_nodes = (int32_t)ctx->nodes.size();
     p->n_tris = (int32_t)ctx->orig.size();
     p->n_flat = ctx->n_flat;
+    p->n_fbox = ctx->n_fbox;
+    std::memcpy(p->fbox_rep, ctx->fbox_rep, sizeof p->fbox_rep);
+    std::memcpy(p->fbox_mask, ctx->fbox_mask, sizeof p->fbox_mask);
     p->stack_entries = stack_entries_for(ctx->interior_depth);
     p->stack_ovf = nullptr;
     p->stack_ovf_lanes = 0;
@@ -1540,6 +1572,7 @@ int pt_get_stat(pt_context* ctx, const char* key, double* out) {
     if (k == "wide_nodes") { *out = (double)ctx->nodes4.size(); return PT_OK; }
     if (k == "wide_pending") { *out = (double)ctx->wide_pending; return PT_OK; }
     if (k == "flat_triangles") { *out = (double)ctx->n_flat; return PT_OK; }
+    if (k == "flat_boxes") { *out = (double)ctx->n_fbox; return PT_OK; }
     if (k == "node_mode") {      // what the next launch will use: 0 whole tree in LDS, 1 L1/L2 only, 2 treelet
         pt_camera cam;
         std::memset(&cam, 0, sizeof cam);

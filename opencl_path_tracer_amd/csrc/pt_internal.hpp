@@ -87,6 +87,9 @@ struct RenderParams {
     int32_t iterations, first_sample, nsamples;
     int32_t n_nodes, n_tris;
     int32_t n_flat;              // packets [0, n_flat) are the big-triangle list: tested by every ray before the tree
+    int32_t n_fbox;              // their distinct boxes (the two triangles of a wall share one): box b is that of packet fbox_rep[b]
+    uint8_t fbox_rep[32];        // and covers the listed triangles in fbox_mask[b]
+    uint32_t fbox_mask[32];
     int32_t node_mode;           // kNodesLds / kNodesGlobal / kNodesTreelet / kNodesWide: where the traversal reads BVH nodes from (and which)
     int32_t treelet_nodes;       // kNodesTreelet: nodes [0, treelet_nodes) are staged in LDS
     int32_t stack_entries;       // per-lane stack entries in LDS: all a BVH2 traversal can need (sentinel + deepest interior node + the slot

@@ -363,7 +363,7 @@ size_t traversal_lds_bytes(const RenderParams& p, int block) {
     b = (b + 15) & ~(size_t)15;
     if (p.node_mode == kNodesLds) b += (size_t)p.n_nodes * 64;
     if (p.node_mode == kNodesTreelet) b += (size_t)p.treelet_nodes * 64;
-    return b + (size_t)p.n_flat * 96;          // the big-triangle list's packets and padded boxes
+    return b + (size_t)p.n_flat * 100;         // the big-triangle list's packets, padded boxes and box-group masks
 }
 
 hipError_t launch_gen_ray(const RenderParams& p, hipStream_t stream) {
