@@ -1209,6 +1209,10 @@ int pt_trace_rays(pt_context* ctx, const pt_camera* cam, int32_t iterations, int
     p.nsamples = 1;
     LaunchConfig lc;
     launch_cfg(ctx, p, &lc);
+    if (ctx->persistent) {      // the grid only fills the chip: a workgroup stages the tree once, not once per eight tiles
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counter, 0, sizeof(uint32_t), ctx->stream));
+        p.tile_counter = ctx->d_tile_counter;
+    }
     EventPair* ep;
     if ((rc = time_begin(ctx, &ep)) != PT_OK) return rc;
     PT_HIP(ctx, launch_trace_ray(p, lc, ctx->stream));
