@@ -229,13 +229,15 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
     const bool chained = p.tile_counter != nullptr && p.chunk_spp > 0;
     const int n_pass = chained ? (p.nsamples + p.chunk_spp - 1) / p.chunk_spp : 1;
     unsigned long long segs = 0, samples = 0, segs_before_item = 0, item_lane_steps = 0;
-    int tile = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    int tile = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     int pass = 0;
     for (;;) {
         if (p.tile_counter) {                                    // ---- fetch the next work item
+            // (the work item is wave-uniform: kept in scalar registers -- readfirstlane, not a lane shuffle -- so that
+            // it is never spilled lane by lane under whatever exec mask the spill happens to land in)
             int t = 0;
             if (lane0) t = (int)atomicAdd(p.tile_counter, 1u);
-            t = __shfl(t, 0, 64);
+            t = __builtin_amdgcn_readfirstlane(t);
             pass = chained ? t / p.n_tiles : 0;
             tile = t - pass * p.n_tiles;
             if (chained ? pass >= n_pass : tile >= p.n_tiles) break;
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
                 unsigned seen = 0;
                 for (;;) {
                     if (lane0) seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    seen = __shfl(seen, 0, 64);
+                    seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
                     if (seen >= (unsigned)pass) break;
                     __builtin_amdgcn_s_sleep(8);
                 }

@@ -806,6 +806,40 @@ def _mesh100k_from_obj(api, oracle, tmp_path, W, H, **ctx_kw):
     return sc, verts, mati
 
 
+@pytest.mark.timeout(300, method="thread")
+@pytest.mark.parametrize("waves", [4, 5, 6])
+def test_register_budgets_of_the_global_memory_kernels(api, oracle, cb_spec, cb_oracle_scene, waves):
+    """Every k_render instance that reads nodes from global memory -- BVH2 and 4-wide nodes, both schedules, with and
+    without chained passes -- at each register budget (4 / 5 / 6 waves per SIMD = 128 / 96 / 80 VGPRs): same frame.
+    (The instances differ in nothing but what the compiler spills; a seventh wave at 72 VGPRs produced a lockstep
+    instance that never returned: profiles/r02/v_seven_waves_per_simd_rejected.txt.)"""
+    from opencl_path_tracer_amd import scenes
+    W, H = 80, 56
+    fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 8, 5)
+    spec = scenes.displaced_grid_mesh(6000)
+    osc = oracle.load_scene(spec)
+    fr2, segs2 = oracle_render(oracle, osc, spec, 64, 64, 6, 3)
+    for schedule in (0, 1):
+        for chunk in (0, 2):
+            sc = api.Scene(W, H).load(cb_spec)
+            for k, v in (("lds_scene", 0), ("waves_per_simd", waves), ("schedule", schedule), ("chunk_spp", chunk)):
+                sc.set_option(k, v)
+            sc.iterations = 8
+            sc.render(5)
+            check(sc, fr, "cornell through L1/L2, %d waves, schedule %d, chunk %d" % (waves, schedule, chunk))
+            assert sc.stat("waves_per_simd") == waves and sc.stat("segments") == segs
+            for wide in (0, 1):
+                sc = api.Scene(64, 64)
+                sc.set_option("wide_nodes", wide)
+                sc.load(spec)
+                for k, v in (("waves_per_simd", waves), ("schedule", schedule), ("chunk_spp", chunk)):
+                    sc.set_option(k, v)
+                sc.iterations = 6
+                sc.render(3)
+                check(sc, fr2, "mesh, wide_nodes %d, %d waves, schedule %d, chunk %d" % (wide, waves, schedule, chunk))
+                assert sc.stat("waves_per_simd") == waves and sc.stat("segments") == segs2
+
+
 def test_config3_mesh_through_add_obj(api, oracle, tmp_path):
     """Triangles authored by pt_add_obj == the array path fed with the same transformed vertices, bit for
     bit; materials == the MTL's; the render == the oracle's on those triangles."""
