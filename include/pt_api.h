@@ -181,10 +181,10 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *   "wide_nodes"   trees read from global memory as 4-wide nodes with 8-bit child boxes (one 64-byte fetch decides two
  *                  BVH2 levels): 1 (default) when the tree does not fit LDS, 0 never, 2 every tree; set before the
  *                  triangles are uploaded
- *   "wide_lds_entries" 4-wide traversal: per-lane stack entries kept in LDS (default 24; the rest of the worst case lives in
- *                  global memory and is touched only by rays that get there); even, 4..24; set before the triangles are uploaded
- *   "waves_per_simd" kernels that read nodes from global memory: register budget for 4, 5 or 6 resident waves per SIMD
- *                  (128 / 96 / 80 VGPRs); -1 (default) the most that the per-lane stacks in LDS leave room for
+ *   "wide_lds_entries" 4-wide traversal: per-lane stack entries kept in LDS (default 20; the rest of the worst case lives in
+ *                  global memory and is touched only by rays that get there); even, 4..20; set before the triangles are uploaded
+ *   "waves_per_simd" kernels that read nodes from global memory: register budget for 4, 5, 6 or 7 resident waves per SIMD
+ *                  (128 / 96 / 80 / 72 VGPRs); -1 (default) the most that the per-lane stacks in LDS leave room for
  *   "persistent"   1 (default) megakernel grid only fills the chip and every wave pulls its next 8x8
  *                  tile from a global counter; 0 one workgroup per group of tiles
  *   "chunk_spp"    persistent megakernel work items: n > 0 (pass, tile) items of n samples, chained per tile

@@ -118,7 +118,7 @@ struct pt_context {
     int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 16 with the whole tree in LDS, else 24)
     int wide_nodes = 1;    // 4-wide quantised nodes: 0 never, 1 for trees that do not fit LDS, 2 for every tree (tests)
     int wide_lds_entries = kWideLdsEntries;   // 4-wide traversal: stack entries per lane kept in LDS (tests lower it to force the global part)
-    int waves_per_simd = -1; // nodes from global memory: register budget for 4 / 5 / 6 waves per SIMD (-1: the most the LDS stacks allow)
+    int waves_per_simd = -1; // nodes from global memory: register budget for 4 / 5 / 6 / 7 waves per SIMD (-1: the most the LDS stacks allow)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
     int bvh_policy = 0;   // 0/1 host SAH with SAH leaf termination, 2 leaves of <= 4, 3 leaves of <= 8, 4 device LBVH
@@ -1172,11 +1172,11 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
     // (1080p over 4 / 8 ranks: 87 % / 62 % strong-scaling efficiency against 73 % / 42 %; over 2 ranks suspend wins again:
     // 95.7 % against 88 %; profiles/r02/e_*, q_*).
     // resident workgroups at 4 waves per SIMD: 2 x 512 threads (whole tree in LDS), 1 x 1024 (treelet) per CU; nodes through
-    // L1/L2 (256 threads): as many waves per SIMD -- 6, 5 or 4 -- as the stacks in LDS leave room for
+    // L1/L2 (256 threads): as many waves per SIMD -- 7, 6, 5 or 4 -- as the stacks in LDS leave room for
     lc->waves_per_simd = 4;
     if (p.node_mode == kNodesGlobal || p.node_mode == kNodesWide) {
-        const int want = ctx->waves_per_simd > 0 ? ctx->waves_per_simd : 6;
-        for (int w = std::min(want, 6); w > 4; --w)
+        const int want = ctx->waves_per_simd > 0 ? ctx->waves_per_simd : 7;
+        for (int w = std::min(want, 7); w > 4; --w)
             if ((size_t)w * lc->lds_bytes + 1024 <= kLdsPerCu) { lc->waves_per_simd = w; break; }
     }
     lc->persistent_blocks = ctx->cu_count * std::max(1, 256 * lc->waves_per_simd / lc->block);
@@ -1508,7 +1508,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         ctx->wide_nodes = (int)value;
         ctx->tris_uploaded = false;                  // the wide nodes are built at upload
     } else if (k == "wide_lds_entries") {
-        if (value < 4 || value > kWideLdsEntries || (value & 1)) return fail(ctx, PT_EINVAL, "wide_lds_entries: even, 4..24");
+        if (value < 4 || value > kWideLdsEntries || (value & 1)) return fail(ctx, PT_EINVAL, "wide_lds_entries: even, 4..20");
         ctx->wide_lds_entries = (int)value;
         ctx->tris_uploaded = false;                  // the global part of the stacks is sized at upload
     } else if (k == "timing") {
@@ -1534,7 +1534,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, "suspend_lanes: -1 default, 0..63");
         ctx->suspend_lanes = (int)value;
     } else if (k == "waves_per_simd") {
-        if (value != -1 && (value < 4 || value > 6)) return fail(ctx, PT_EINVAL, "waves_per_simd: -1 automatic, 4..6 (kernels that read nodes from global memory)");
+        if (value != -1 && (value < 4 || value > 7)) return fail(ctx, PT_EINVAL, "waves_per_simd: -1 automatic, 4..7 (kernels that read nodes from global memory)");
         ctx->waves_per_simd = (int)value;
     } else if (k == "debug_repeat") {
         if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "debug_repeat: 0..1000 extra timed launches");

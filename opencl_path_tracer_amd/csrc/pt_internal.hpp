@@ -53,7 +53,7 @@ struct Node4q {
 };
 static_assert(sizeof(Node4q) == 64, "Node4q must be 64 B");
 constexpr int32_t kWideNoChild = ~0;      // the leaf {packet 0, 1 triangle}: always present (an empty scene holds one all-zero packet)
-constexpr int kWideLdsEntries = 24;   // 24 x 4 B x 256 lanes = 24 KB per workgroup: six workgroups per CU next to the big-triangle list
+constexpr int kWideLdsEntries = 20;   // 20 x 4 B x 256 lanes = 20 KB per workgroup: seven workgroups per CU next to the big-triangle list
 bool build_wide_nodes(const std::vector<Node64>& bvh2, std::vector<Node4q>* out, int* max_pending);   // pt_wide.cpp
 
 // Where the traversal reads BVH nodes from (Trav<MODE> in pt_device.hpp)
@@ -150,7 +150,7 @@ struct LaunchConfig {
     int persistent_blocks = 1 << 30;   // grid size of a persistent launch (workgroups that fit the chip)
     bool count_work = false;           // also count node visits / triangle tests into stats[2..9]
     int schedule = 0;                  // megakernel: 0 lockstep per sample, 1 restart + tail suspension (pt_kernels.hip)
-    int waves_per_simd = 4;            // register budget of the k_render instance: 4, or 5 / 6 for nodes from global memory
+    int waves_per_simd = 4;            // register budget of the k_render instance: 4, or 5 / 6 / 7 for nodes from global memory
 };
 
 // launchers (pt_kernels.hip, pt_wavefront.hip, pt_debug.hip); all asynchronous on `stream`

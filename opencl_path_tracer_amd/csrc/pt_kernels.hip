@@ -209,9 +209,10 @@ PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, con
 //    L2 write-back, tile_done[tile] = pass + 1) and acquire (consumer: poll, L1 invalidate, loads).
 //    The host guarantees n_pass * n_tiles + (resident waves) < 2^31 (pt_render).
 // WPS = waves per SIMD the register budget is set for (512 / WPS VGPRs): 4 where the kernel is bound by VALU
-// issue (nodes in LDS); 5 or 6 for nodes from global memory, where every wave-level step is a dependent memory
-// round trip and a fifth / sixth wave hides more of it than the extra spills cost (MESH-100k +16 %, MESH-1M +13 %;
-// the same step lost 30 % on the Cornell box: profiles/r02/t_*, v_*).
+// issue (nodes in LDS); 5, 6 or 7 for nodes from global memory, where every wave-level step is a dependent memory
+// round trip and another resident wave hides more of it than the extra spills cost (4 -> 5 -> 6 waves: MESH-100k
+// 630 / 698 / 727 with BVH2 nodes, a seventh +1-2 %, an eighth loses; the step from 4 to 5 lost 30 % on the Cornell
+// box: profiles/r02/t_*, v_*).
 template <bool SPLIT, int MODE, int BLOCK, bool COUNT, int SCHED, int WPS>
 __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
     LaneStack<typename StackOf<MODE>::type> stk;
@@ -399,10 +400,12 @@ static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc,
     switch (p.node_mode) {
     case kNodesLds: return launch_one<SPLIT, kNodesLds, 512, COUNT, SCHED, 4>(p, lc, stream);
     case kNodesGlobal:
+        if (lc.waves_per_simd == 7) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 7>(p, lc, stream);
         if (lc.waves_per_simd == 6) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 6>(p, lc, stream);
         if (lc.waves_per_simd == 5) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 5>(p, lc, stream);
         return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 4>(p, lc, stream);
     case kNodesWide:
+        if (lc.waves_per_simd == 7) return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 7>(p, lc, stream);
         if (lc.waves_per_simd == 6) return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 6>(p, lc, stream);
         if (lc.waves_per_simd == 5) return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 5>(p, lc, stream);
         return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 4>(p, lc, stream);

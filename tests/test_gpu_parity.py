@@ -768,7 +768,7 @@ def test_schedules_identical(api, oracle, cb_spec, cb_oracle_scene, schedule, k)
     spec = scenes.displaced_grid_mesh(6000)
     osc = oracle.load_scene(spec)
     fr2, segs2 = oracle_render(oracle, osc, spec, 64, 64, 6, 3)
-    for wide, lds_entries in ((0, 24), (1, 24), (1, 4)):       # BVH2 through L1/L2; 4-wide nodes, stacks in LDS / mostly in global memory
+    for wide, lds_entries in ((0, 20), (1, 20), (1, 4)):       # BVH2 through L1/L2; 4-wide nodes, stacks in LDS / mostly in global memory
         sc = api.Scene(64, 64)
         sc.set_option("wide_nodes", wide)
         sc.set_option("wide_lds_entries", lds_entries)
@@ -807,12 +807,12 @@ def _mesh100k_from_obj(api, oracle, tmp_path, W, H, **ctx_kw):
 
 
 @pytest.mark.timeout(300, method="thread")
-@pytest.mark.parametrize("waves", [4, 5, 6])
+@pytest.mark.parametrize("waves", [4, 5, 6, 7])
 def test_register_budgets_of_the_global_memory_kernels(api, oracle, cb_spec, cb_oracle_scene, waves):
     """Every k_render instance that reads nodes from global memory -- BVH2 and 4-wide nodes, both schedules, with and
-    without chained passes -- at each register budget (4 / 5 / 6 waves per SIMD = 128 / 96 / 80 VGPRs): same frame.
-    (The instances differ in nothing but what the compiler spills; a seventh wave at 72 VGPRs produced a lockstep
-    instance that never returned: profiles/r02/v_seven_waves_per_simd_rejected.txt.)"""
+    without chained passes -- at each register budget (4 / 5 / 6 / 7 waves per SIMD = 128 / 96 / 80 / 72 VGPRs): same
+    frame.  (The instances differ in nothing but what the compiler spills -- which is how a wave-uniform work item kept
+    in a VGPR came back wrong from a spill made under a partial exec mask: profiles/r02/v_seven_waves_*.)"""
     from opencl_path_tracer_amd import scenes
     W, H = 80, 56
     fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 8, 5)

@@ -11,7 +11,7 @@ for w in (4, 5, 6):
     run(1920, 1080, 8, 64, cb, reps=2, lds_scene=0, waves_per_simd=w)
 for name, n, b, spp in (("mesh100k", 100000, 8, 16), ("mesh1m", 1000000, 16, 8)):
     m = scenes.displaced_grid_mesh(n)
-    for w in (4, 5, 6):
+    for w in (4, 5, 6, 7):
         for k in (16, 24, 32):
             run(1920, 1080, b, spp, m, reps=2, waves_per_simd=w, suspend_lanes=k)
     run(1920, 1080, b, spp, m, reps=2, schedule=0)

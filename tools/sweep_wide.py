@@ -12,7 +12,7 @@ for name, n, b, spp in (("mesh100k", 100000, 8, 16), ("mesh1m", 1000000, 16, 8))
         continue
     m = scenes.displaced_grid_mesh(n)
     for wide in (0, 1):
-        for w in (4, 5, 6):
+        for w in (4, 5, 6, 7):
             run(1920, 1080, b, spp, m, reps=2, wide_nodes=wide, waves_per_simd=w)
     run(1920, 1080, b, spp, m, reps=2, wide_nodes=1, wide_lds_entries=16)
     run(1920, 1080, b, spp, m, reps=2, wide_nodes=1, suspend_lanes=16)
