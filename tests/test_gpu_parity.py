@@ -781,7 +781,7 @@ def test_schedules_identical(api, oracle, cb_spec, cb_oracle_scene, schedule, k)
         assert sc.stat("segments") == segs2
 
 
-def _mesh100k_from_obj(api, oracle, tmp_path, W, H, **ctx_kw):
+def _mesh100k_from_obj(api, oracle, tmp_path, W, H, pre=None, **ctx_kw):
     """BASELINE config 3 as SURVEY 8(d) words it: the Cornell walls authored with add_Triangle
     (main.cpp:793-815) + MESH-100k written as OBJ+MTL (Kd/Ks/Ke/Ns/Kn/Kk/Tp, shared vertices, three usemtl
     bands) and loaded with pt_add_obj under a non-trivial pos/scale/pitch/yaw.  Returns the product scene,
@@ -794,6 +794,8 @@ def _mesh100k_from_obj(api, oracle, tmp_path, W, H, **ctx_kw):
     verts = world[faces]
     mati = (len(scenes.BUILTIN_MATERIALS) + band).astype(np.uint16)        # mat_offset, main.cpp:562
     sc = api.Scene(W, H, **ctx_kw)
+    for k, v in (pre or {}).items():           # options the upload depends on
+        sc.set_option(k, v)
     for m in scenes.BUILTIN_MATERIALS:
         sc.add_Material(*m)
     wv, wm = scenes.cornell_walls()
@@ -872,17 +874,21 @@ def test_config3_mesh_through_add_obj(api, oracle, tmp_path):
 
 def test_full_size_properties_mesh_1080p(api, oracle, tmp_path):
     """BASELINE config 3 at full size (OBJ-loaded MESH-100k, 1920x1080, 8 bounces): k samples in one launch
-    == k launches of one == the same under the other schedule / another suspension threshold; the union of
-    two ranks' tiles == the single-context frame."""
+    == k launches of one == the same under the other schedule / another suspension threshold == the same from
+    other kernel instances (BVH2 nodes at 4 waves per SIMD in lockstep; 4-wide nodes at 5 / 6 with chained passes of
+    one sample) ; the union of two ranks' tiles == the single-context frame."""
     W, H, B = 1920, 1080, 8
     a, _, _ = _mesh100k_from_obj(api, oracle, tmp_path, W, H)
     a.iterations = B
     a.render(3)
     ca, ra = a.read_colors(), a.read_rnds()
     assert float(ca[:, :3].sum()) > 0
+    a_mode, a_waves = a.stat("node_mode"), a.stat("waves_per_simd")
     del a
-    for opts in ({"steps": 3}, {"schedule": 0}, {"suspend_lanes": 8}):
-        b, _, _ = _mesh100k_from_obj(api, oracle, tmp_path, W, H)
+    assert a_mode == 3 and a_waves == 7
+    for opts in ({"steps": 3}, {"schedule": 0}, {"suspend_lanes": 8}, {"pre": {"wide_nodes": 0}, "waves_per_simd": 4, "schedule": 0},
+                 {"waves_per_simd": 5, "schedule": 0, "chunk_spp": 1}, {"waves_per_simd": 6, "chunk_spp": 1}):
+        b, _, _ = _mesh100k_from_obj(api, oracle, tmp_path, W, H, pre=opts.pop("pre", None))
         steps = opts.pop("steps", 1)
         for k, v in opts.items():
             b.set_option(k, v)
