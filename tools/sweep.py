@@ -8,7 +8,7 @@ from opencl_path_tracer_amd import api, scenes  # noqa: E402
 
 def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
     sc = api.Scene(W, H)
-    pre = ("bvh_policy", "treelet", "flat_list", "wide_nodes", "wide_lds_entries")    # options the upload depends on
+    pre = ("bvh_policy", "treelet", "flat_list", "wide_nodes", "wide_lds_entries", "sah_visit_cost")    # options the upload depends on
     for k in pre:
         if k in opts:
             sc.set_option(k, opts[k])
