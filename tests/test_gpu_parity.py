@@ -327,9 +327,12 @@ def test_deep_paths(api, oracle, cb_spec, cb_oracle_scene, variant):
     assert sc.stat("segments") == segs
 
 
+@pytest.mark.parametrize("nonfinite", [False, True])
 @pytest.mark.parametrize("wide", [1, 2])
-def test_degenerate_triangles(api, oracle, wide):
-    """Zero-area triangles (two coincident vertices; three collinear ones) and a needle among ordinary ones: their
+def test_degenerate_triangles(api, oracle, wide, nonfinite):
+    """(nonfinite: three more triangles with an inf, a -inf and a NaN coordinate -- the product keeps them out of the
+    tree, their boxes being the biggest of all, and tests them with the exact arithmetic, as the exhaustive search does.)
+    Zero-area triangles (two coincident vertices; three collinear ones) and a needle among ordinary ones: their
     normals are NaN (main.cpp:146-150 normalises a zero cross product), no ray can hit them (every comparison of
     prog.cl:94-112 is false), and neither the builders nor the 8-bit boxes of the 4-wide nodes may trip over them."""
     from opencl_path_tracer_amd import scenes
@@ -355,6 +358,12 @@ def test_degenerate_triangles(api, oracle, wide):
                     [a.tolist(), ((a + b) / 2).tolist(), b.tolist()] if kind == 1 else
                     [a.tolist(), (a + 1e-4).tolist(), b.tolist()])
         mati.append(diffuse)
+    if nonfinite:
+        for bad in (np.inf, -np.inf, np.nan):
+            t = rng.uniform(100, 900, (3, 3))
+            t[rng.randint(3), rng.randint(3)] = bad
+            tris.append(t.tolist())
+            mati.append(diffuse)
     tris = np.asarray(tris, dtype=np.float32)
     mati = np.asarray(mati, dtype=np.uint16)
     W, H = 48, 32
