@@ -12,7 +12,7 @@ HDRS    := $(CSRC)/pt_internal.hpp $(CSRC)/pt_device.hpp include/pt_api.h
 OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 
 $(PKG)/libptamd.so: $(OBJS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS) -ldl
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS) -ldl -lpthread
 
 build/%.o: $(CSRC)/% $(HDRS)
 	@mkdir -p build
@@ -23,7 +23,7 @@ build/%.o: $(CSRC)/% $(HDRS)
 ab:
 	@mkdir -p build/ab_$(AB)
 	for f in $(SRCS); do $(HIPCC) $(HIPFLAGS) $(ABFLAGS) -c -o build/ab_$(AB)/$$(basename $$f).o $$f & done; wait
-	$(HIPCC) $(HIPFLAGS) -shared -o $(PKG)/libptamd_$(AB).so build/ab_$(AB)/*.o -ldl
+	$(HIPCC) $(HIPFLAGS) -shared -o $(PKG)/libptamd_$(AB).so build/ab_$(AB)/*.o -ldl -lpthread
 
 tests/cpp/dropin: tests/cpp/dropin_main.cpp include/pt_scene.hpp include/pt_api.h $(PKG)/libptamd.so
 	g++ -O1 -std=c++14 -Iinclude -o $@ tests/cpp/dropin_main.cpp -L$(PKG) -lptamd -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -Wl,-rpath,/opt/rocm/lib

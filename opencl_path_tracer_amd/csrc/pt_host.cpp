@@ -15,6 +15,7 @@
 #include "pt_internal.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -22,6 +23,7 @@
 #include <limits>
 #include <numeric>
 #include <queue>
+#include <thread>
 
 using namespace ptamd;
 
@@ -116,6 +118,7 @@ struct pt_context {
     int flat_list = 16;        // at most this many big triangles go to the flat list (option flat_list; 0: none)
     int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
     int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 16 with the whole tree in LDS, else 24)
+    int build_threads = 0; // host SAH builder: threads (0: the machine's, at most 16); the tree is the same for any number
     int wide_nodes = 1;    // 4-wide quantised nodes: 0 never, 1 for trees that do not fit LDS, 2 for every tree (tests)
     int wide_lds_entries = kWideLdsEntries;   // 4-wide traversal: stack entries per lane kept in LDS (tests lower it to force the global part)
     int waves_per_simd = -1; // nodes from global memory: register budget for 4 / 5 / 6 / 7 waves per SIMD (-1: the most the LDS stacks allow)
@@ -269,23 +272,29 @@ struct BvhBuilder {
         return l;
     }
 
-    int32_t make_leaf(size_t lo, size_t hi) {
-        int32_t first = (int32_t)order.size();
-        for (size_t i = lo; i < hi; ++i) order.push_back(prims[i].tri);
-        int32_t count = (int32_t)(hi - lo);
+    // A leaf's packed position follows from its range: the recursion visits [lo, hi) ranges in ascending order and
+    // every primitive ends up in exactly one leaf, so leaf [lo, hi) holds packed triangles order_base + lo ...
+    // (`order` itself is filled from the final arrangement of `prims`, finish_order()).
+    int32_t order_base = 0;
+    int32_t make_leaf(size_t lo, size_t hi) const {
+        const int32_t first = order_base + (int32_t)lo;
+        const int32_t count = (int32_t)(hi - lo);
         return ~((first << 3) | (count - 1));
     }
+    void finish_order() {
+        order.resize((size_t)order_base + prims.size());
+        for (size_t i = 0; i < prims.size(); ++i) order[(size_t)order_base + i] = prims[i].tri;
+    }
 
-    // returns child reference; *box receives the bounds of the subtree
-    int32_t build(size_t lo, size_t hi, int depth, Aabb* box) {
-        max_depth_seen = std::max(max_depth_seen, depth);
+    // Bounds of [lo, hi) and, unless the range becomes a leaf (returns false), its partition point.
+    bool split(size_t lo, size_t hi, int depth, Aabb* box, size_t* mid_out) {
         const size_t n = hi - lo;
         Aabb b, cb;
         b.reset();
         cb.reset();
         for (size_t i = lo; i < hi; ++i) { b.grow(prims[i].box); cb.grow(prims[i].c); }
         *box = b;
-        if (n <= 1) return make_leaf(lo, hi);
+        if (n <= 1) return false;
 
         // --- binned SAH over the three axes
         constexpr int NB = 16;
@@ -321,7 +330,7 @@ struct BvhBuilder {
         }
         // SAH termination: a node visit (64 B, two slab tests) is priced like one exact triangle test
         const float leaf_cost = b.half_area() * (float)n;
-        if (n <= (size_t)max_leaf && (force_leaf || !(best_cost + visit_cost * b.half_area() < leaf_cost))) return make_leaf(lo, hi);
+        if (n <= (size_t)max_leaf && (force_leaf || !(best_cost + visit_cost * b.half_area() < leaf_cost))) return false;
 
         size_t mid = lo;
         bool median = (best_axis < 0);
@@ -345,17 +354,123 @@ struct BvhBuilder {
             std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
                              [a](const BuildPrim& x, const BuildPrim& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.tri < y.tri); });
         }
-        int32_t me = (int32_t)nodes.size();
-        nodes.emplace_back();
-        Aabb lb, rb;
-        int32_t l = build(lo, mid, depth + 1, &lb);
-        int32_t r = build(mid, hi, depth + 1, &rb);
-        Node64& nd = nodes[me];
+        *mid_out = mid;
+        return true;
+    }
+
+    static void set_children(Node64& nd, int32_t l, int32_t r, const Aabb& lb, const Aabb& rb) {
         for (int a = 0; a < 3; ++a) { nd.q[a][0] = lb.lo[a]; nd.q[a][1] = lb.hi[a]; nd.q[a][2] = rb.lo[a]; nd.q[a][3] = rb.hi[a]; }
         nd.left = l;
         nd.right = r;
         nd.pad[0] = nd.pad[1] = 0;
+    }
+
+    // Subtree of [lo, hi) appended to `out` in preorder; returns the child reference (index into `out`, or a leaf),
+    // *box receives the bounds, *deepest the depth of the deepest range.
+    int32_t build_into(std::vector<Node64>& out, int* deepest, size_t lo, size_t hi, int depth, Aabb* box) {
+        *deepest = std::max(*deepest, depth);
+        size_t mid;
+        if (!split(lo, hi, depth, box, &mid)) return make_leaf(lo, hi);
+        const int32_t me = (int32_t)out.size();
+        out.emplace_back();
+        Aabb lb, rb;
+        const int32_t l = build_into(out, deepest, lo, mid, depth + 1, &lb);
+        const int32_t r = build_into(out, deepest, mid, hi, depth + 1, &rb);
+        set_children(out[(size_t)me], l, r, lb, rb);
         return me;
+    }
+    int32_t build(size_t lo, size_t hi, int depth, Aabb* box) { return build_into(nodes, &max_depth_seen, lo, hi, depth, box); }
+
+    // The same tree, node for node, from several threads: the top of the tree is split serially down to ranges of at most
+    // `grain` primitives, the ranges are built concurrently (they are disjoint slices of `prims`) into private node
+    // arrays, and a last preorder walk splices them into `nodes` (interior references move by the splice offset; leaf
+    // references are positions and do not move).
+    struct Part {
+        int kind;               // 0 leaf reference, 1 top node, 2 task
+        int32_t v;              // the reference / index into tops / index into tasks
+        Aabb box;
+    };
+    struct TopNode { Part l, r; };
+    struct Task {
+        size_t lo, hi;
+        int depth;
+        std::vector<Node64> out;
+        int32_t root = 0;
+        int deepest = 0;
+        Aabb box;
+    };
+    Part split_top(std::vector<TopNode>& tops, std::vector<Task>& tasks, size_t grain, size_t lo, size_t hi, int depth) {
+        Part p;
+        if (hi - lo <= grain) {
+            p.kind = 2;
+            p.v = (int32_t)tasks.size();
+            tasks.emplace_back();
+            tasks.back().lo = lo;
+            tasks.back().hi = hi;
+            tasks.back().depth = depth;
+            return p;
+        }
+        max_depth_seen = std::max(max_depth_seen, depth);
+        size_t mid;
+        if (!split(lo, hi, depth, &p.box, &mid)) {
+            p.kind = 0;
+            p.v = make_leaf(lo, hi);
+            return p;
+        }
+        p.kind = 1;
+        p.v = (int32_t)tops.size();
+        tops.emplace_back();
+        const Part l = split_top(tops, tasks, grain, lo, mid, depth + 1);
+        const Part r = split_top(tops, tasks, grain, mid, hi, depth + 1);
+        tops[(size_t)p.v].l = l;
+        tops[(size_t)p.v].r = r;
+        return p;
+    }
+    int32_t splice(const std::vector<TopNode>& tops, const std::vector<Task>& tasks, const Part& p, Aabb* box) {
+        if (p.kind == 0) { *box = p.box; return p.v; }
+        if (p.kind == 2) {
+            const Task& t = tasks[(size_t)p.v];
+            *box = t.box;
+            if (t.root < 0) return t.root;
+            const int32_t off = (int32_t)nodes.size();
+            for (Node64 nd : t.out) {
+                if (nd.left >= 0) nd.left += off;
+                if (nd.right >= 0) nd.right += off;
+                nodes.push_back(nd);
+            }
+            return off + t.root;
+        }
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Aabb lb, rb;
+        const int32_t l = splice(tops, tasks, tops[(size_t)p.v].l, &lb);
+        const int32_t r = splice(tops, tasks, tops[(size_t)p.v].r, &rb);
+        set_children(nodes[(size_t)me], l, r, lb, rb);
+        Aabb b = lb;
+        b.grow(rb);
+        *box = b;
+        return me;
+    }
+    int32_t build_parallel(int threads, Aabb* box) {
+        const size_t n = prims.size();
+        const size_t grain = std::max<size_t>(4096, n / ((size_t)threads * 8));
+        std::vector<TopNode> tops;
+        std::vector<Task> tasks;
+        const Part root = split_top(tops, tasks, grain, 0, n, 0);
+        std::atomic<size_t> next(0);
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < tasks.size(); i = next.fetch_add(1)) {
+                Task& t = tasks[i];
+                t.out.reserve(t.hi - t.lo);
+                t.root = build_into(t.out, &t.deepest, t.lo, t.hi, t.depth, &t.box);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int k = 1; k < threads; ++k) pool.emplace_back(work);
+        work();
+        for (std::thread& th : pool) th.join();
+        for (const Task& t : tasks) max_depth_seen = std::max(max_depth_seen, t.deepest);
+        return splice(tops, tasks, root, box);
     }
 };
 
@@ -386,6 +501,7 @@ int build_attempt(pt_context* ctx, BvhBuilder& bld, const std::vector<BuildPrim>
     bld.nodes.reserve(prims.size());
     bld.order.reserve(prims.size() + flat.size());
     bld.order = flat;            // the flat list comes first in packed order; leaf ranges start behind it
+    bld.order_base = (int32_t)flat.size();
     // The root must be an interior node: wrap a leaf / an empty scene.
     Aabb lb, rb;
     lb.reset();
@@ -403,9 +519,12 @@ int build_attempt(pt_context* ctx, BvhBuilder& bld, const std::vector<BuildPrim>
         if (l >= 0) return fail(ctx, PT_ESCENE, "internal: small scene did not become a leaf");
     } else {
         Aabb box;
-        int32_t root = bld.build(0, bld.prims.size(), 0, &box);
+        int threads = ctx->build_threads > 0 ? ctx->build_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (bld.prims.size() < 32768) threads = 1;
+        int32_t root = threads > 1 ? bld.build_parallel(threads, &box) : bld.build(0, bld.prims.size(), 0, &box);
         if (root != 0) return fail(ctx, PT_ESCENE, "internal: BVH root is not node 0");
     }
+    bld.finish_order();
     return PT_OK;
 }
 
@@ -1503,6 +1622,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < -1 || value > 2048) return fail(ctx, PT_EINVAL, "treelet: 0 off, -1 as many nodes as fit, 2..2048 nodes");
         ctx->treelet = (int)value;
         ctx->tris_uploaded = false;                  // the tree is re-indexed at upload
+    } else if (k == "build_threads") {
+        if (value < 0 || value > 256) return fail(ctx, PT_EINVAL, "build_threads: 0 automatic, 1..256");
+        ctx->build_threads = (int)value;
     } else if (k == "wide_nodes") {
         if (value < 0 || value > 2) return fail(ctx, PT_EINVAL, "wide_nodes: 0 never, 1 for trees that do not fit LDS, 2 always");
         ctx->wide_nodes = (int)value;

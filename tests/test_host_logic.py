@@ -122,6 +122,26 @@ def test_wide_nodes_contain_the_bvh2(api, cb_spec, which):
     assert sc2.stat("node_mode") == (3 if which != "cornell" else 0)
 
 
+def test_threaded_build_gives_the_same_tree(api):
+    """The host SAH builder splits the top of the tree serially, builds the ranges below concurrently and splices them in
+    preorder: node for node the tree of the single-threaded build (leaf references are positions, not append order)."""
+    from opencl_path_tracer_amd import scenes
+    spec = scenes.displaced_grid_mesh(100000)
+    ref = None
+    for threads in (1, 3, 8):
+        sc = api.Scene(16, 16, device=None)
+        sc.set_option("build_threads", threads)
+        sc.load(spec)
+        nodes, tris, meta, orig = sc.debug_bvh()
+        if ref is None:
+            ref = (nodes, tris, meta, orig, sc.stat("bvh_depth"))
+            bvh_check.validate_structure(nodes, tris, spec.ntris, int(sc.stat("flat_triangles")))
+            continue
+        assert np.array_equal(nodes.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(orig, ref[3])
+        assert np.array_equal(tris.view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(meta, ref[2])
+        assert sc.stat("bvh_depth") == ref[4]
+
+
 def test_flat_list_selection(api, cb_spec):
     """The big-triangle list: the m biggest triangles, each >= 1/16 of the box around all the others.  Cornell
     box: the 10 wall / floor / ceiling triangles AND the 2 lamp triangles (the lamp is small, but not against
