@@ -177,7 +177,7 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *                  when at most "suspend_lanes" lanes are unfinished (they resume in the next trip); 0 lockstep: all
  *                  lanes of a wave start a sample together; -1 (default) 1 when the context has >= 3 tiles per
  *                  resident wave (one or two GPUs at 1080p), else 0
- *   "suspend_lanes" -1 (default: 16 with the whole tree in LDS, otherwise 24), 0..63
+ *   "suspend_lanes" -1 (default: 24), 0..63
  *   "build_threads" host SAH builder: 0 (default) as many threads as the machine has (at most 16), 1..256; the tree is
  *                  the same, node for node, for any number
  *   "wide_nodes"   trees read from global memory as 4-wide nodes with 8-bit child boxes (one 64-byte fetch decides two

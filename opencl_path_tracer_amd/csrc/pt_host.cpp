@@ -117,7 +117,7 @@ struct pt_context {
     int sah_visit_cost = 10;   // tenths of a triangle test (option sah_visit_cost)
     int flat_list = 16;        // at most this many big triangles go to the flat list (option flat_list; 0: none)
     int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
-    int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 16 with the whole tree in LDS, else 24)
+    int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 24)
     int build_threads = 0; // host SAH builder: threads (0: the machine's, at most 16); the tree is the same for any number
     int wide_nodes = 1;    // 4-wide quantised nodes: 0 never, 1 for trees that do not fit LDS, 2 for every tree (tests)
     int wide_lds_entries = kWideLdsEntries;   // 4-wide traversal: stack entries per lane kept in LDS (tests lower it to force the global part)
@@ -859,7 +859,8 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->n_tiles = ((ctx->W + 7) / 8) * ((ctx->local_rows + 7) / 8);
     // measured with the big-triangle list in place (profiles/r02/i_*): Cornell box in LDS 8 / 16 / 24 / 32 -> 1669 / 1690 /
     // 1680 / 1669 Msamples/s (lockstep 1671); MESH-100k 24 / 32 / 48 -> 600 / 599 / 595 (lockstep 571); MESH-1M 211 / 210 / 205 (191)
-    p->suspend_lanes = ctx->suspend_lanes >= 0 ? ctx->suspend_lanes : (p->node_mode == kNodesLds ? 16 : 24);
+    // (re-swept at the end of the round: Cornell box 8 / 12 / 16 / 20 / 24 / 32 -> 1957 / 2033 / 2066 / 2074 / 2078 / 2070)
+    p->suspend_lanes = ctx->suspend_lanes >= 0 ? ctx->suspend_lanes : 24;
 }
 
 int check_ready(pt_context* ctx, const pt_camera* cam) {
