@@ -169,10 +169,11 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *   "bvh_policy"   0 host SAH (default), 2 / 3 host SAH with leaves forced to <= 4 / <= 8 triangles, 4 device LBVH;
  *                  set before the triangles are uploaded
  *   "lds_scene"    2 (default) every workgroup stages BVH nodes in LDS: the whole tree when it fits (<= 64 KB,
- *                  <= 4096 triangles), otherwise its top if "treelet" asks for one; 0 every node through L1/L2
+ *                  <= 4096 triangles), otherwise its top if "treelet" asks for one (else the nodes are read through
+ *                  L1/L2, see "wide_nodes"); 0 every node through L1/L2
  *   "treelet"      nodes of a LARGE tree to stage in LDS (the ones with the biggest boxes, renumbered to the front):
- *                  0 (default) none -- with the big-triangle list in place it no longer pays --, -1 what fits next to
- *                  one 1,024-thread workgroup's stacks (~750-1,000), 2..2048; set before the triangles are uploaded
+ *                  0 (default) none -- slower than 4-wide nodes through L1/L2 --, -1 what fits next to one
+ *                  1,024-thread workgroup's stacks (~750-1,000), 2..2048; set before the triangles are uploaded
  *   "schedule"     megakernel: 1 a lane whose path ended starts its next sample at once and the wave leaves a traversal
  *                  when at most "suspend_lanes" lanes are unfinished (they resume in the next trip); 0 lockstep: all
  *                  lanes of a wave start a sample together; -1 (default) 1 when the context has >= 3 tiles per
@@ -190,7 +191,8 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *   "persistent"   1 (default) megakernel grid only fills the chip and every wave pulls its next 8x8
  *                  tile from a global counter; 0 one workgroup per group of tiles
  *   "chunk_spp"    persistent megakernel work items: n > 0 (pass, tile) items of n samples, chained per tile
- *                  through memory inside ONE launch; 0 whole tiles; -1 (default) automatic
+ *                  through memory inside ONE launch; 0 whole tiles; -1 (default) by tiles per resident wave: 32 from 5
+ *                  (64 when a launch has >= 256 samples), 16 from 3, 8 above 1.5, otherwise whole tiles
  *   "sah_visit_cost"  SAH price of one node visit in tenths of a triangle test (default 10; set before
  *                  the triangles are uploaded.  Measured: 5 / 10 / 15 / 20 -> 1006 / 1448 / 1393 / 1266 Msamples/s)
  *   "cost_binning" 0/1 wavefront: separate ray streams for rays touching a complex object's box
@@ -200,10 +202,13 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *   "debug_repeat" 0..1000 extra timed launches in pt_debug_closest_hit */
 int pt_set_option(pt_context* ctx, const char* key, int64_t value);
 /* stats: "segments" path segments executed since the last reset, "samples", "kernel_ms" (sum of
- * HIP-event durations of the dominant kernel), "kernel_launches", "bvh_nodes", "bvh_depth", "stack_entries" (per-lane traversal stack: deepest interior node + 2),
- * "bvh_build_ms", "bvh_on_device", "triangles", "lds_bytes", "waves_per_simd", "node_mode" (0 whole tree in LDS, 1 L1/L2 only,
- * 2 treelet, 3 4-wide nodes through L1/L2), "treelet_nodes", "wide_nodes" (how many 4-wide nodes), "flat_triangles", and with count_work: "node_visits", "tri_tests", "wave_node_steps",
- * "wave_tri_steps", "tile_lane_steps" */
+ * HIP-event durations of the dominant kernel), "kernel_launches", "bvh_nodes", "bvh_depth", "stack_entries"
+ * (per-lane BVH2 traversal stack: deepest interior node + 2), "bvh_build_ms" (pt_upload_triangles as a whole),
+ * "bvh_on_device", "triangles", "lds_bytes", "waves_per_simd", "node_mode" (0 whole tree in LDS, 1 BVH2 nodes through
+ * L1/L2, 2 treelet, 3 4-wide nodes through L1/L2), "treelet_nodes", "wide_nodes" (how many 4-wide nodes),
+ * "wide_pending" (their worst-case stack), "flat_triangles", "flat_boxes" (their distinct bounding boxes), and with
+ * count_work: "node_visits", "tri_tests", "wave_node_steps", "wave_tri_steps", "tile_lane_steps", "wave_shade_steps",
+ * "wave_trips", "wave_rounds" */
 int pt_get_stat(pt_context* ctx, const char* key, double* out);
 
 /* ---- introspection for tests (host data; no device work) ----------------------------- */
