@@ -179,6 +179,9 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *                  lanes of a wave start a sample together; -1 (default) 1 when the context has >= 3 tiles per
  *                  resident wave (one or two GPUs at 1080p), else 0
  *   "suspend_lanes" -1 (default: 24), 0..63
+ *   "lbvh_cluster" device-built trees (bvh_policy 4): the top of the tree above clusters of at most this many triangles is
+ *                  rebuilt with the host's SAH over the cluster boxes (default 64; 0: the LBVH as the device built it);
+ *                  set before the triangles are uploaded
  *   "build_threads" host SAH builder: 0 (default) as many threads as the machine has (at most 16), 1..256; the tree is
  *                  the same, node for node, for any number
  *   "wide_nodes"   trees read from global memory as 4-wide nodes with 8-bit child boxes (one 64-byte fetch decides two

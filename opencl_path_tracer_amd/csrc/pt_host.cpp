@@ -118,6 +118,7 @@ struct pt_context {
     int flat_list = 16;        // at most this many big triangles go to the flat list (option flat_list; 0: none)
     int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
     int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 24)
+    int lbvh_cluster = 64;  // device-built trees: the top above clusters of this many triangles is rebuilt with the host SAH (0: not)
     int build_threads = 0; // host SAH builder: threads (0: the machine's, at most 16); the tree is the same for any number
     int wide_nodes = 1;    // 4-wide quantised nodes: 0 never, 1 for trees that do not fit LDS, 2 for every tree (tests)
     int wide_lds_entries = kWideLdsEntries;   // 4-wide traversal: stack entries per lane kept in LDS (tests lower it to force the global part)
@@ -1119,6 +1120,111 @@ int pt_end_obj(pt_context* ctx) {
     return PT_OK;
 }
 
+// Device-built trees (bvh_policy 4): the LBVH splits by Morton code, which is good inside small clusters and poor at the top,
+// where boxes overlap most.  The tree is cut into clusters of at most `cluster` triangles (maximal subtrees of the radix
+// tree), and the top above the cut is rebuilt with the host's binned SAH over the cluster boxes -- a few thousand
+// primitives, milliseconds -- and spliced onto the untouched cluster subtrees.  Leaves, packets and their order stay as the
+// device emitted them.  Returns false (tree unchanged) when there is nothing to gain or the result would be too deep.
+static bool sah_top_rebuild(pt_context* ctx, int cluster) {
+    std::vector<Node64>& old = ctx->nodes;
+    if (cluster <= 0 || old.size() < 64) return false;
+    // triangles below every node (post-order over an explicit stack; children are visited before their parent is closed)
+    std::vector<int32_t> count(old.size(), 0);
+    {
+        std::vector<std::pair<int32_t, int>> st;
+        st.emplace_back(0, 0);
+        while (!st.empty()) {
+            const int32_t i = st.back().first;
+            const int phase = st.back().second;
+            const Node64& nd = old[(size_t)i];
+            if (phase == 0) {
+                st.back().second = 1;
+                if (nd.left >= 0) st.emplace_back(nd.left, 0);
+                if (nd.right >= 0) st.emplace_back(nd.right, 0);
+            } else {
+                const int32_t cl = nd.left >= 0 ? count[(size_t)nd.left] : ((~nd.left) & 7) + 1;
+                const int32_t cr = nd.right >= 0 ? count[(size_t)nd.right] : ((~nd.right) & 7) + 1;
+                count[(size_t)i] = cl + cr;
+                st.pop_back();
+            }
+        }
+    }
+    if (count[0] <= cluster * 4) return false;
+    // the cut: children that are leaves or small enough become clusters
+    struct Cluster { int32_t ref; Aabb box; };
+    std::vector<Cluster> clusters;
+    {
+        std::vector<int32_t> st(1, 0);
+        while (!st.empty()) {
+            const int32_t i = st.back();
+            st.pop_back();
+            const Node64& nd = old[(size_t)i];
+            for (int side = 0; side < 2; ++side) {
+                const int32_t c = side ? nd.right : nd.left;
+                Cluster cl;
+                cl.ref = c;
+                for (int a = 0; a < 3; ++a) { cl.box.lo[a] = nd.q[a][2 * side]; cl.box.hi[a] = nd.q[a][2 * side + 1]; }
+                if (!(cl.box.lo[0] <= cl.box.hi[0] && cl.box.lo[1] <= cl.box.hi[1] && cl.box.lo[2] <= cl.box.hi[2])) continue;   // empty child
+                if (c >= 0 && count[(size_t)c] > cluster) st.push_back(c);
+                else clusters.push_back(cl);
+            }
+        }
+    }
+    if (clusters.size() < 4) return false;
+    BvhBuilder top;
+    top.prims.resize(clusters.size());
+    for (size_t k = 0; k < clusters.size(); ++k) {
+        BuildPrim& p = top.prims[k];
+        p.box = clusters[k].box;
+        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.box.lo[a] + p.box.hi[a]);
+        p.tri = (int32_t)k;
+    }
+    top.max_leaf = 1;            // one cluster per leaf of the top tree
+    top.force_leaf = false;
+    top.visit_cost = (float)ctx->sah_visit_cost * 0.1f;
+    Aabb box;
+    if (top.build(0, top.prims.size(), 0, &box) != 0) return false;
+    // splice: top nodes in preorder, every cluster's subtree copied right where the top tree refers to it
+    std::vector<Node64> out;
+    out.reserve(old.size() + top.nodes.size());
+    struct Copy {
+        const std::vector<Node64>& old;
+        std::vector<Node64>& out;
+        int32_t subtree(int32_t ref) {
+            if (ref < 0) return ref;
+            const int32_t me = (int32_t)out.size();
+            out.push_back(old[(size_t)ref]);
+            const int32_t l = subtree(old[(size_t)ref].left), r = subtree(old[(size_t)ref].right);
+            out[(size_t)me].left = l;
+            out[(size_t)me].right = r;
+            return me;
+        }
+    } copy{old, out};
+    struct Emit {
+        const BvhBuilder& top;
+        const std::vector<Cluster>& clusters;
+        Copy& copy;
+        std::vector<Node64>& out;
+        int32_t child(int32_t ref) {
+            if (ref >= 0) return node(ref);
+            const int32_t pos = (~ref) >> 3;                              // a top leaf holds one primitive: the cluster at that position
+            return copy.subtree(clusters[(size_t)top.prims[(size_t)pos].tri].ref);
+        }
+        int32_t node(int32_t t) {
+            const int32_t me = (int32_t)out.size();
+            out.push_back(top.nodes[(size_t)t]);
+            const int32_t l = child(top.nodes[(size_t)t].left), r = child(top.nodes[(size_t)t].right);
+            out[(size_t)me].left = l;
+            out[(size_t)me].right = r;
+            return me;
+        }
+    } emit{top, clusters, copy, out};
+    emit.node(0);
+    if (deepest_interior_node(out) + 2 > kStackEntries) return false;
+    old.swap(out);
+    return true;
+}
+
 // bvh_policy 4: build the tree on the device (pt_lbvh.hip); host copies are kept for the debug getters
 static int build_on_device(pt_context* ctx, bool* done) {
     *done = false;
@@ -1185,9 +1291,11 @@ static int build_on_device(pt_context* ctx, bool* done) {
             if (nd.right < 0) nd.right -= nf << 3;
         }
     }
+    const bool retopped = sah_top_rebuild(ctx, ctx->lbvh_cluster);
     int rc = plan_node_placement(ctx);
     if (rc != PT_OK) { drop(); return rc; }
-    if (nf > 0) {                 // recomposed on the host: replace the builder's device arrays
+    if (retopped) ctx->bvh_depth = ctx->interior_depth + 1;
+    if (nf > 0 || retopped) {     // recomposed on the host: replace the builder's device arrays
         (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta);
         if ((rc = upload_vec(ctx, &ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size())) != PT_OK) return rc;
         if ((rc = upload_vec(ctx, &ctx->d_tris, ctx->packets.data(), sizeof(TriPacket) * ctx->packets.size())) != PT_OK) return rc;
@@ -1623,6 +1731,10 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < -1 || value > 2048) return fail(ctx, PT_EINVAL, "treelet: 0 off, -1 as many nodes as fit, 2..2048 nodes");
         ctx->treelet = (int)value;
         ctx->tris_uploaded = false;                  // the tree is re-indexed at upload
+    } else if (k == "lbvh_cluster") {
+        if (value < 0 || value > (1 << 20)) return fail(ctx, PT_EINVAL, "lbvh_cluster: 0 off, 1..2^20 triangles");
+        ctx->lbvh_cluster = (int)value;
+        ctx->tris_uploaded = false;
     } else if (k == "build_threads") {
         if (value < 0 || value > 256) return fail(ctx, PT_EINVAL, "build_threads: 0 automatic, 1..256");
         ctx->build_threads = (int)value;
