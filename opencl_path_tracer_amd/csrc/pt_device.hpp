@@ -675,12 +675,8 @@ PT_DEV int closest_hit(const SceneView& sv, f3 P, f3 D, const LaneStack<typename
 }
 
 // ---------------------------------------------------------------------------- BSDF sampling
-struct RayPD {
-    f3 P, D;
-};
-
 // prog.cl:186-218
-PT_DEV RayPD new_ray_diffuse(f3 hp, f3 N, float rnd1, float rnd2) {
+PT_DEV f3 diffuse_direction(f3 N, float rnd1, float rnd2) {       // prog.cl:205-218 up to the normalisation (shade_hit does it)
     const float E = 0.001f;
     const bool yaxis = __builtin_fabsf(N.x) <= E && __builtin_fabsf(N.z) <= E;
     const float other = yaxis ? N.y : N.x;
@@ -695,10 +691,7 @@ PT_DEV RayPD new_ray_diffuse(f3 hp, f3 N, float rnd1, float rnd2) {
     f3 d = X * x;
     d = madd(N, z, d);
     d = madd(Z, y, d);
-    RayPD o;
-    o.P = madd(N, E, hp);
-    o.D = normalize3(d);
-    return o;
+    return d;
 }
 
 // prog.cl:219-222
@@ -706,34 +699,6 @@ PT_DEV f3 fresnel(f3 F0, f3 N, f3 D) {
     const float cosa = __builtin_fabsf(dot3(N, D));
     const float p5 = spec_pow5(1.0f - cosa);
     return mk(fmaf_(1.0f - F0.x, p5, F0.x), fmaf_(1.0f - F0.y, p5, F0.y), fmaf_(1.0f - F0.z, p5, F0.z));
-}
-
-// prog.cl:223-227
-PT_DEV RayPD new_ray_specular(f3 hp, f3 N, f3 oldD) {
-    const float cosa = dot3(N, oldD);
-    RayPD o;
-    o.D = normalize3(oldD - (N * cosa) * 2.0f);
-    o.P = madd(N, 0.001f, hp);
-    return o;
-}
-
-// prog.cl:228-245; *flipped = the path crossed the interface (in = !in)
-PT_DEV RayPD new_ray_refractive(f3 hp, f3 N, f3 F0, float n, f3 oldD, bool in, float rnd, bool* flipped) {
-    if (in) n = 1.0f / n;
-    const float cosa = dot3(-oldD, N);
-    const float disc = 1.0f - (fmaf_(-cosa, cosa, 1.0f) / n) / n;
-    const f3 F = fresnel(F0, N, oldD);
-    const float prob = ((F.x + F.y) + F.z) / 3.0f;
-    const bool refr = disc > 0.0f && rnd > prob;
-    *flipped = refr;
-    // both candidate directions before normalisation; one normalize serves either branch
-    const f3 dn = mk(oldD.x / n, oldD.y / n, oldD.z / n);
-    const f3 dr = madd(N, cosa / n - __builtin_sqrtf(disc), dn);
-    const f3 dm = oldD - (N * dot3(N, oldD)) * 2.0f;
-    RayPD o;
-    o.D = normalize3(refr ? dr : dm);
-    o.P = madd(N, refr ? -0.001f : 0.001f, hp);
-    return o;
 }
 
 // ---------------------------------------------------------------------------- path state + shading
@@ -750,40 +715,26 @@ PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, c
     const int type = m->type;
     if (p.iterations == 1) color = ldf3(m->kd) + ldf3(m->emission);         // prog.cl:323-325
     if (dot3(rD, N) > 0.0f) N = -N;                                         // prog.cl:326-328
-    if (type == 0 || type == 3) {
+    // Every material that continues the path ends the same way: normalise the new direction, step off the surface
+    // along +-N.  The two sampling branches below only produce the direction BEFORE normalisation and the side; the
+    // tail is shared, so a wave that holds both kinds of hit runs one normalisation (IEEE sqrt + divide), not two.
+    const bool lobe = type == 0 || type == 3, spec = type == 1 || type == 2;
+    f3 dnew = rD;
+    float side = 0.001f;
+    float inten = 0.0f;
+    if (lobe) {
         // diffuse (prog.cl:329-340) and emitter (prog.cl:358-366) both continue with a cosine-
         // sampled ray drawn from two LCG values; the emitter's cosine uses the OLD direction.
-        const float inten = max0(dot3(-rD, N));
+        inten = max0(dot3(-rD, N));
         const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
-        const RayPD nr = new_ray_diffuse(hp, N, rnd1, rnd2);
-        if (type == 0) {
-            const float idiff = max0(dot3(nr.D, N));
-            fL = fL * (ldf3(m->kd) * idiff);
-            // m->_pad = 1: ks is exactly 0 and shininess is finite >= 0, so ks * pow(...) is +-0 whatever the
-            // (finite) power is -- skip the halfway vector (two normalisations) and the double-precision pow
-            // (set by pt_upload_materials)
-            float pw = 1.0f;
-            if (!m->_pad) {
-                const f3 view = normalize3(ldf3(p.cam.eye) - hp);
-                const f3 halfway = normalize3(view + nr.D);
-                const float ispec = max0(dot3(N, halfway));
-                pw = spec_pow(ispec, m->shininess);
-            }
-            fB = fB * (ldf3(m->ks) * pw);
-        } else {
-            const f3 e = ((ldf3(m->emission) * (fL + fB)) * fS) * fR;
-            color = madd(e, inten, color);
-        }
-        rP = nr.P;
-        rD = nr.D;
-    } else if (type == 1 || type == 2) {
+        dnew = diffuse_direction(N, rnd1, rnd2);
+    } else if (spec) {
         // mirror (prog.cl:341-345) and dielectric (prog.cl:346-357, 228-245) share the Fresnel
         // term and the mirror direction; the dielectric may pick the refracted direction instead.
         const f3 oldD = rD;
         const f3 F0 = ldf3(m->F0);
         const f3 F = fresnel(F0, N, oldD);
-        f3 dsel = oldD - (N * dot3(N, oldD)) * 2.0f;
-        bool refr = false;
+        dnew = oldD - (N * dot3(N, oldD)) * 2.0f;
         if (type == 2) {
             float n = m->n;
             if (inside) n = 1.0f / n;
@@ -791,13 +742,14 @@ PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, c
             const float cosa = dot3(-oldD, N);
             const float disc = 1.0f - (fmaf_(-cosa, cosa, 1.0f) / n) / n;
             const float prob = ((F.x + F.y) + F.z) / 3.0f;
-            refr = disc > 0.0f && rnd > prob;
+            const bool refr = disc > 0.0f && rnd > prob;
             if (refr) {
                 const f3 dn = mk(oldD.x / n, oldD.y / n, oldD.z / n);
-                dsel = madd(N, cosa / n - __builtin_sqrtf(disc), dn);
+                dnew = madd(N, cosa / n - __builtin_sqrtf(disc), dn);
                 const float k = 1.0f / (1.0f - prob);
                 fR = (fR * mk(1.0f - F.x, 1.0f - F.y, 1.0f - F.z)) * k;
                 inside = !inside;
+                side = -0.001f;
             } else {
                 const float k = 1.0f / prob;
                 fR = (fR * F) * k;
@@ -805,8 +757,28 @@ PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, c
         } else {
             fS = fS * F;
         }
-        rD = normalize3(dsel);
-        rP = madd(N, refr ? -0.001f : 0.001f, hp);
+    }
+    if (lobe || spec) {
+        rD = normalize3(dnew);
+        rP = madd(N, side, hp);
+    }
+    if (type == 0) {
+        const float idiff = max0(dot3(rD, N));
+        fL = fL * (ldf3(m->kd) * idiff);
+        // m->_pad = 1: ks is exactly 0 and shininess is finite >= 0, so ks * pow(...) is +-0 whatever the
+        // (finite) power is -- skip the halfway vector (two normalisations) and the double-precision pow
+        // (set by pt_upload_materials)
+        float pw = 1.0f;
+        if (!m->_pad) {
+            const f3 view = normalize3(ldf3(p.cam.eye) - hp);
+            const f3 halfway = normalize3(view + rD);
+            const float ispec = max0(dot3(N, halfway));
+            pw = spec_pow(ispec, m->shininess);
+        }
+        fB = fB * (ldf3(m->ks) * pw);
+    } else if (type == 3) {
+        const f3 e = ((ldf3(m->emission) * (fL + fB)) * fS) * fR;
+        color = madd(e, inten, color);
     }
     // any other type: the ray is left unchanged and the loop hits the same surface again
 }
