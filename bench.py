@@ -106,12 +106,14 @@ def cpu_baseline(width, height, bounces, target_s):
 def kernel_source_sha():
     import hashlib
     h = hashlib.sha256()
-    for f in ("pt_device.hpp", "pt_kernels.hip", "pt_internal.hpp"):
+    # device code AND the host code that picks the kernel instance and its launch shape (schedule, pass length, waves per
+    # SIMD, node layout): a change in either invalidates counters measured under the old one
+    for f in ("pt_device.hpp", "pt_kernels.hip", "pt_wavefront.hip", "pt_internal.hpp", "pt_host.cpp", "pt_wide.cpp"):
         h.update(open(os.path.join(ROOT, "opencl_path_tracer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
-def tracked_counters(W, H, B, spp):
+def tracked_counters(W, H, B, spp, prefix="cornell"):
     """rocprofv3 PMC summary of the same launch shape (tools/pmc_record.py), or None.  `stale` = the kernel
     sources are not the ones it was measured with."""
     path = os.path.join(ROOT, "profiles", "counters.json")
@@ -119,7 +121,7 @@ def tracked_counters(W, H, B, spp):
         tj = json.load(open(path))
     except (OSError, ValueError):
         return None
-    c = tj.get("cornell_%dx%d_b%d_spp%d" % (W, H, B, spp))
+    c = tj.get("%s_%dx%d_b%d_spp%d" % (prefix, W, H, B, spp))
     if not c:
         return None
     c = dict(c)
@@ -224,8 +226,9 @@ def main():
         for _ in range(nside):
             sc.render(args.spp_per_step)
         torch.cuda.synchronize(dev)
+        side_dt = time.perf_counter() - t1
         other = {"variant": "wavefront" if ov == 1 else "megakernel",
-                 "msamples_per_s": W * H * args.spp_per_step * nside / (time.perf_counter() - t1) / 1e6}
+                 "msamples_per_s": W * H * args.spp_per_step * nside / side_dt / 1e6, "ms_per_step": side_dt / nside * 1e3}
         sc.set_option("variant", args.variant)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
@@ -285,6 +288,22 @@ def main():
                                      "valu_insts_per_launch": counters["valu_insts_per_launch"],
                                      "source": counters["source"], "measured_at": counters["measured_at"], "stale": counters["stale"]}
         if other is not None:
+            # the other formulation's own HBM roofline.  Wavefront: SURVEY 8(d)'s stream model, 32 B/sample + 200 B/segment
+            # over ALL its kernels (generate, intersect, shade) per step; traffic = the tracked PMC bytes of one sample pass
+            # x spp (profiles/counters.json key wavefront_*, tools/pmc_record.py), null when stale or absent.
+            if other["variant"] == "wavefront":
+                obytes = (BYTES_PER_SAMPLE + BYTES_PER_SEGMENT * dbar) * W * H * args.spp_per_step
+                omodel = "SURVEY 8(d): 32 B/sample + 200 B/segment, all wavefront kernels of a step"
+                oc = tracked_counters(W, H, B, 1, prefix="wavefront_cornell")
+                otraffic = oc["hbm_bytes_per_launch"] * args.spp_per_step if oc and not oc["stale"] else None
+            else:
+                obytes = MEGA_BYTES_PER_SAMPLE * W * H * args.spp_per_step
+                omodel = "SURVEY 8(d): megakernel 40 B/sample"
+                otraffic = None
+            oach = obytes / (other["ms_per_step"] * 1e-3) / 1e9
+            other["roofline"] = {"bound": "hbm", "achieved": oach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": oach / HBM_PEAK_GBS,
+                                 "traffic": otraffic, "algorithmic_bytes_per_step": obytes, "model": omodel,
+                                 "time": "wall clock of the untimed side run (all launches of a step)"}
             line["other_variant"] = other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(W, H, B, args.cpu_seconds)

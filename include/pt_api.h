@@ -137,12 +137,15 @@ int pt_resolve_ldr(pt_context* ctx, int32_t which, float* out_rgba, int64_t npix
  *   a file, torch.distributed ...); every rank: pt_comm_init(ctx, id); after rendering, every rank:
  *   pt_gather_frame(ctx) -- ONE ncclAllGather of the ranks' radiance slabs over RCCL/xGMI on the context's
  *   stream + a de-interleave kernel -- leaves the whole width x height frame (float3 @ 16 B, global pixel
- *   order) in device memory on every rank.  world = 1 needs no communicator. */
+ *   order) in device memory on every rank.  world = 1 needs no communicator.
+ * The gathered frame is served (pt_device_frame, pt_read_frame, pt_write_*) only until the next call that renders: after
+ * that a one-rank context serves its colors buffer (which IS the frame) and a tiled context returns NULL / PT_EINVAL
+ * until pt_gather_frame has run again -- never a frame older than colors. */
 #define PT_COMM_ID_BYTES 128
 int pt_comm_unique_id(void* id128);                                  /* ncclGetUniqueId */
 int pt_comm_init(pt_context* ctx, const void* id128);                /* ncclCommInitRank(world, id, rank) of pt_create_tiled */
 int pt_gather_frame(pt_context* ctx);
-void* pt_device_frame(pt_context* ctx);                              /* the assembled frame (world = 1: the colors buffer) */
+void* pt_device_frame(pt_context* ctx);                              /* the assembled frame (world = 1 without a fresh gather: the colors buffer); NULL if stale */
 int pt_frame_size(const pt_context* ctx, int32_t* width, int32_t* height, int64_t* npix);
 int pt_read_frame(pt_context* ctx, float* out_rgba, int64_t npix);   /* npix = width * height of the GLOBAL frame */
 

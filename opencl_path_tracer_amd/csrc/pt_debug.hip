@@ -27,10 +27,9 @@ template <int MODE, int BLOCK>
 static hipError_t launch_debug_t(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, int cu_count, hipStream_t stream) {
     const size_t lds = traversal_lds_bytes(p, BLOCK);
     auto kern = k_debug_closest_hit<MODE, BLOCK>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    static LdsMark mark;
+    const hipError_t e = ensure_dynamic_lds((const void*)kern, mark, lds);
+    if (e != hipSuccess) return e;
     const long long need = (n + BLOCK - 1) / BLOCK;
     const int blocks = (int)std::min<long long>(need, (long long)cu_count * (2048 / BLOCK));
     if (p.stack_ovf && (long long)blocks * BLOCK > (long long)p.stack_ovf_lanes) return hipErrorInvalidValue;

@@ -48,26 +48,39 @@ PT_DEV f3 normalize3(f3 a) {
 PT_DEV float max0(float c) { return c > 0.0f ? c : 0.0f; }
 
 // ---- spec math: double polynomials, rounded once to float
+// The polynomial coefficients are 64-bit literals, which no gfx950 VALU instruction can encode: left alone, the compiler
+// keeps each in a VGPR pair for the whole kernel (hoisted out of every loop) and, in the instances with 72-96 VGPRs,
+// spills them -- ten 8-byte scratch reloads per lane in front of every cosine-sampled direction, each wave with its own
+// copy of the same constants (~180 KB per CU fighting the nodes for L1 / L2).  KC<true>() pins a coefficient to a scalar
+// register pair at its point of use instead: two s_mov_b32 with literal operands, then v_fma_f64 reads the pair directly.
+// SK = false leaves the constants to the compiler: the 128-VGPR instance (whole tree in LDS) has room for them and is
+// 1 % faster that way (profiles/r03/d_*).
+template <bool SK>
+PT_DEV double KC(double c) {
+    if (SK) asm volatile("" : "+s"(c));
+    return c;
+}
+template <bool SK>
 PT_DEV void spec_sincos(float theta, float* s, float* c) {
     const double t = (double)theta;
-    const int q = (int)fmad_(t, 0.63661977236758138, 0.5);
+    const int q = (int)fmad_(t, KC<SK>(0.63661977236758138), 0.5);
     const double qd = (double)q;
-    double r = fmad_(qd, -1.5707963267948966, t);
-    r = fmad_(qd, -6.123233995736766e-17, r);
+    double r = fmad_(qd, KC<SK>(-1.5707963267948966), t);
+    r = fmad_(qd, KC<SK>(-6.123233995736766e-17), r);
     const double z = r * r;
-    double ps = 1.6059043836821613e-10;
-    ps = fmad_(ps, z, -2.505210838544172e-08);
-    ps = fmad_(ps, z, 2.7557319223985893e-06);
-    ps = fmad_(ps, z, -0.0001984126984126984);
-    ps = fmad_(ps, z, 0.008333333333333333);
-    ps = fmad_(ps, z, -0.16666666666666666);
+    double ps = KC<SK>(1.6059043836821613e-10);
+    ps = fmad_(ps, z, KC<SK>(-2.505210838544172e-08));
+    ps = fmad_(ps, z, KC<SK>(2.7557319223985893e-06));
+    ps = fmad_(ps, z, KC<SK>(-0.0001984126984126984));
+    ps = fmad_(ps, z, KC<SK>(0.008333333333333333));
+    ps = fmad_(ps, z, KC<SK>(-0.16666666666666666));
     const double sr = fmad_(r * z, ps, r);
-    double pc = -1.1470745597729725e-11;
-    pc = fmad_(pc, z, 2.08767569878681e-09);
-    pc = fmad_(pc, z, -2.755731922398589e-07);
-    pc = fmad_(pc, z, 2.48015873015873e-05);
-    pc = fmad_(pc, z, -0.001388888888888889);
-    pc = fmad_(pc, z, 0.041666666666666664);
+    double pc = KC<SK>(-1.1470745597729725e-11);
+    pc = fmad_(pc, z, KC<SK>(2.08767569878681e-09));
+    pc = fmad_(pc, z, KC<SK>(-2.755731922398589e-07));
+    pc = fmad_(pc, z, KC<SK>(2.48015873015873e-05));
+    pc = fmad_(pc, z, KC<SK>(-0.001388888888888889));
+    pc = fmad_(pc, z, KC<SK>(0.041666666666666664));
     pc = fmad_(pc, z, -0.5);
     const double cr = fmad_(z, pc, 1.0);
     const int k = q & 3;
@@ -83,6 +96,7 @@ PT_DEV float spec_pow5(float x) {
     return x4 * x;
 }
 
+template <bool SK>
 PT_DEV float spec_pow(float x, float y) {
     if (y == 0.0f) return 1.0f;
     if (x != x || y != y) return __builtin_nanf("");
@@ -94,37 +108,37 @@ PT_DEV float spec_pow(float x, float y) {
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
     bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
     double m = __longlong_as_double((long long)bits);
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    if (m > KC<SK>(1.4142135623730951)) { m = m * 0.5; e += 1; }
     const double f = m - 1.0;
     const double sdiv = f / (2.0 + f);
     const double z = sdiv * sdiv;
-    double p = 0.10526315789473684;
-    p = fmad_(p, z, 0.11764705882352941);
-    p = fmad_(p, z, 0.13333333333333333);
-    p = fmad_(p, z, 0.15384615384615385);
-    p = fmad_(p, z, 0.18181818181818182);
-    p = fmad_(p, z, 0.22222222222222221);
-    p = fmad_(p, z, 0.2857142857142857);
-    p = fmad_(p, z, 0.4);
-    p = fmad_(p, z, 0.66666666666666663);
+    double p = KC<SK>(0.10526315789473684);
+    p = fmad_(p, z, KC<SK>(0.11764705882352941));
+    p = fmad_(p, z, KC<SK>(0.13333333333333333));
+    p = fmad_(p, z, KC<SK>(0.15384615384615385));
+    p = fmad_(p, z, KC<SK>(0.18181818181818182));
+    p = fmad_(p, z, KC<SK>(0.22222222222222221));
+    p = fmad_(p, z, KC<SK>(0.2857142857142857));
+    p = fmad_(p, z, KC<SK>(0.4));
+    p = fmad_(p, z, KC<SK>(0.66666666666666663));
     p = fmad_(p, z, 2.0);
     const double lnm = sdiv * p;
-    const double lg2 = fmad_(lnm, 1.4426950408889634, (double)e);
+    const double lg2 = fmad_(lnm, KC<SK>(1.4426950408889634), (double)e);
     const double w = (double)y * lg2;
     if (!(w > -126.0)) return 0.0f;
     if (w >= 128.0) return __builtin_inff();
     const double nd = __builtin_floor(w + 0.5);
-    const double g = (w - nd) * 0.6931471805599453;
-    double q = 2.08767569878681e-09;
-    q = fmad_(q, g, 2.505210838544172e-08);
-    q = fmad_(q, g, 2.755731922398589e-07);
-    q = fmad_(q, g, 2.7557319223985893e-06);
-    q = fmad_(q, g, 2.48015873015873e-05);
-    q = fmad_(q, g, 0.0001984126984126984);
-    q = fmad_(q, g, 0.001388888888888889);
-    q = fmad_(q, g, 0.008333333333333333);
-    q = fmad_(q, g, 0.041666666666666664);
-    q = fmad_(q, g, 0.16666666666666666);
+    const double g = (w - nd) * KC<SK>(0.6931471805599453);
+    double q = KC<SK>(2.08767569878681e-09);
+    q = fmad_(q, g, KC<SK>(2.505210838544172e-08));
+    q = fmad_(q, g, KC<SK>(2.755731922398589e-07));
+    q = fmad_(q, g, KC<SK>(2.7557319223985893e-06));
+    q = fmad_(q, g, KC<SK>(2.48015873015873e-05));
+    q = fmad_(q, g, KC<SK>(0.0001984126984126984));
+    q = fmad_(q, g, KC<SK>(0.001388888888888889));
+    q = fmad_(q, g, KC<SK>(0.008333333333333333));
+    q = fmad_(q, g, KC<SK>(0.041666666666666664));
+    q = fmad_(q, g, KC<SK>(0.16666666666666666));
     q = fmad_(q, g, 0.5);
     q = fmad_(q, g, 1.0);
     q = fmad_(q, g, 1.0);
@@ -203,6 +217,9 @@ PT_DEV void camera_get_ray(int id, const pt_camera& cam, float rnd1, float rnd2,
 }
 
 // ---------------------------------------------------------------------------- traversal
+// dynamic LDS of every traversal kernel: [per-lane stacks][staged nodes][big-triangle list] (setup_traversal)
+extern __shared__ __attribute__((aligned(16))) unsigned char pt_lds_raw[];
+
 // Where the BVH nodes are read from (template parameter of Trav and of the kernels):
 //   kNodesLds      every node is staged in LDS by the workgroup (stage_nodes), re-laid out for the
 //                  ray (swizzled box quads, 16-bit child references, 16-bit stack entries).  Scenes
@@ -227,8 +244,11 @@ struct SceneView {
     const unsigned* lds_fmask; // ... and which listed triangles each one covers
     // kNodesWide: the lane's stack continues in global memory past its LDS entries (a 4-wide traversal can have three
     // children pending per level, far more than it usually has; LDS holds what keeps six waves per SIMD resident)
-    const char* stk_end;       // the lane's first stack address past its LDS entries
-    unsigned* ovf;             // entry (LDS entries + j) of this lane = ovf[j * ovf_stride]
+    // (all three wave-uniform, i.e. scalar registers: which entry an address is, and whose, is read off the address
+    // itself -- the stacks start at LDS offset 0, entry k of lane l at (k * BLOCK + l) * 4 -- so that no per-lane
+    // pointer rides through the traversal)
+    int lds_entries;           // entries per lane in LDS
+    unsigned* ovf;             // entry (lds_entries + j) of lane l of this workgroup = ovf[j * ovf_stride + l]
     unsigned ovf_stride;
 };
 
@@ -317,7 +337,9 @@ struct Trav {
     int stride;    // bytes between entries
     int cur;
     int pend;      // round(): a leaf met during the node phase and not yet intersected (0: none)
-    int onx, ony, onz;   // byte offset of the entry-plane pair of each axis inside a staged node; 8 / 24 / 40 = direction negative
+    int onx, ony, onz;   // kNodesLds only: byte offset of the entry-plane pair of each axis inside a staged node; 8 / 24 / 40 = direction
+                         // negative.  The other modes read the sign bits of `inv` where they need them (ox / oy / oz, negx / negy /
+                         // negz): three registers fewer across a traversal, at the same instruction count
     f3 cn, cf;           // -(P * inv) widened down / up (entry / exit distance = fma(plane, inv, c))
 
     PT_DEV static bool is_node(int c) { return kRef16 ? c < 0x7fff : (unsigned)c < 0x7fffffffu; }
@@ -343,9 +365,11 @@ struct Trav {
         P = P_;
         D = D_;
         inv = mk(__builtin_amdgcn_rcpf(D_.x), __builtin_amdgcn_rcpf(D_.y), __builtin_amdgcn_rcpf(D_.z));
-        onx = __float_as_int(inv.x) < 0 ? 8 : 0;
-        ony = __float_as_int(inv.y) < 0 ? 24 : 16;
-        onz = __float_as_int(inv.z) < 0 ? 40 : 32;
+        if (kRef16) {
+            onx = __float_as_int(inv.x) < 0 ? 8 : 0;
+            ony = __float_as_int(inv.y) < 0 ? 24 : 16;
+            onz = __float_as_int(inv.z) < 0 ? 40 : 32;
+        }
         // Distance to a plane as ONE fma: plane * inv - P * inv.  The product P * inv is rounded
         // (half an ulp of |P * inv|, which can dwarf the distance itself), so the entry constant
         // is lowered and the exit constant raised by 4 such half-ulps: entry distances come out
@@ -361,6 +385,12 @@ struct Trav {
         cn = mk(-(px + ex), -(py + ey), -(pz + ez));
         cf = mk(-(px - ex), -(py - ey), -(pz - ez));
     }
+    PT_DEV bool negx() const { return __float_as_int(inv.x) < 0; }
+    PT_DEV bool negy() const { return __float_as_int(inv.y) < 0; }
+    PT_DEV bool negz() const { return __float_as_int(inv.z) < 0; }
+    PT_DEV int ox() const { return kRef16 ? onx : (negx() ? 8 : 0); }
+    PT_DEV int oy() const { return kRef16 ? ony : (negy() ? 24 : 16); }
+    PT_DEV int oz() const { return kRef16 ? onz : (negz() ? 40 : 32); }
     PT_DEV void idle() { cur = kDone; }
     PT_DEV bool done() const { return cur == kDone; }
 
@@ -422,7 +452,7 @@ struct Trav {
                 qr = *reinterpret_cast<const float4*>(nb + (off + 48u));
             }
 #if PT_GLOBAL_SLAB_FMA
-            const bool sx = onx == 8, sy = ony == 24, sz = onz == 40;
+            const bool sx = negx(), sy = negy(), sz = negz();
             const float lnx = sx ? qx.y : qx.x, lfx = sx ? qx.x : qx.y, rnx = sx ? qx.w : qx.z, rfx = sx ? qx.z : qx.w;
             const float lny = sy ? qy.y : qy.x, lfy = sy ? qy.x : qy.y, rny = sy ? qy.w : qy.z, rfy = sy ? qy.z : qy.w;
             const float lnz = sz ? qz.y : qz.x, lfz = sz ? qz.x : qz.y, rnz = sz ? qz.w : qz.z, rfz = sz ? qz.z : qz.w;
@@ -478,15 +508,21 @@ struct Trav {
     // the stack farthest first.  All three stores are unconditional (a child that was missed lands above the new
     // top, where it is never read), so the stack has room for top + 3 at every visit (wide_stack_entries()).
     // stack entry at address `at`, which may lie past the lane's LDS entries (kNodesWide only)
+    PT_DEV int entry_of(const char* at) const {      // which stack entry an address is (stride = BLOCK x 4 B, a power of two)
+        return (int)((unsigned)(at - reinterpret_cast<const char*>(pt_lds_raw)) >> (31 - __builtin_clz(stride)));
+    }
+    PT_DEV unsigned lane_of(const char* at) const {  // whose: the thread index inside the workgroup
+        return ((unsigned)(at - reinterpret_cast<const char*>(pt_lds_raw)) & (unsigned)(stride - 1)) >> 2;
+    }
     PT_DEV int stack_get(const SceneView& sv, const char* at) const {
-        const int d = (int)(at - sv.stk_end);
-        if (MODE != kNodesWide || d < 0) return (int)*reinterpret_cast<const StackT*>(at);
-        return (int)sv.ovf[(size_t)(d >> (31 - __builtin_clz(stride))) * sv.ovf_stride];      // (stride = 256 lanes x 4 B)
+        const int j = MODE == kNodesWide ? entry_of(at) - sv.lds_entries : -1;
+        if (j < 0) return (int)*reinterpret_cast<const StackT*>(at);
+        return (int)sv.ovf[(size_t)j * sv.ovf_stride + lane_of(at)];
     }
     PT_DEV void stack_put(const SceneView& sv, char* at, int v) const {
-        const int d = (int)(at - sv.stk_end);
-        if (MODE != kNodesWide || d < 0) *reinterpret_cast<StackT*>(at) = (StackT)v;
-        else sv.ovf[(size_t)(d >> (31 - __builtin_clz(stride))) * sv.ovf_stride] = (unsigned)v;
+        const int j = MODE == kNodesWide ? entry_of(at) - sv.lds_entries : -1;
+        if (j < 0) *reinterpret_cast<StackT*>(at) = (StackT)v;
+        else sv.ovf[(size_t)j * sv.ovf_stride + lane_of(at)] = (unsigned)v;
     }
 
     template <bool COUNT>
@@ -494,7 +530,7 @@ struct Trav {
         const float kWiden = 1.0000005f;
         // does any lane of the wave come within three entries of the end of its LDS part?  (rare: then every stack
         // access of this visit goes through the checked accessors)
-        const bool tight = __ballot(tos + 3 * stride >= sv.stk_end) != 0;
+        const bool tight = __ballot(entry_of(tos) + 3 >= sv.lds_entries) != 0;
         const int top = tight ? stack_get(sv, tos) : (int)*reinterpret_cast<const StackT*>(tos);
         if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; }
         const char* nb = reinterpret_cast<const char*>(sv.nodes);
@@ -506,7 +542,7 @@ struct Trav {
         const unsigned eb = (unsigned)__float_as_int(h.w);
         const float sx = __int_as_float((int)((eb & 0xffu) << 23)), sy = __int_as_float((int)(((eb >> 8) & 0xffu) << 23));
         const float sz = __int_as_float((int)(((eb >> 16) & 0xffu) << 23));
-        const bool ngx = onx == 8, ngy = ony == 24, ngz = onz == 40;
+        const bool ngx = negx(), ngy = negy(), ngz = negz();
         const unsigned enx = ngx ? qa.y : qa.x, exx = ngx ? qa.x : qa.y;
         const unsigned eny = ngy ? qa.w : qa.z, exy = ngy ? qa.z : qa.w;
         const unsigned enz = ngz ? qb.y : qb.x, exz = ngz ? qb.x : qb.y;
@@ -596,12 +632,13 @@ struct Trav {
     PT_DEV void flat_pass(const SceneView& sv, WorkCount* wc) {
         const float kWiden = 1.0000005f;
         unsigned mask = 0;
+        const int fx = ox(), fy = oy(), fz = oz();
 #pragma clang loop unroll(disable) vectorize(disable)      // (unrolled x8 it spills 40 registers around the loop)
         for (int i = 0; i < sv.n_fbox; ++i) {
             const char* bb = sv.lds_fbox + i * 48;
-            const float2 x = *reinterpret_cast<const float2*>(bb + onx);      // (entry plane, exit plane) of the axis
-            const float2 y = *reinterpret_cast<const float2*>(bb + ony);
-            const float2 z = *reinterpret_cast<const float2*>(bb + onz);
+            const float2 x = *reinterpret_cast<const float2*>(bb + fx);      // (entry plane, exit plane) of the axis
+            const float2 y = *reinterpret_cast<const float2*>(bb + fy);
+            const float2 z = *reinterpret_cast<const float2*>(bb + fz);
             const float tn = fmaxf(fmaxf(fmaf_(x.x, inv.x, cn.x), fmaf_(y.x, inv.y, cn.y)), fmaf_(z.x, inv.z, cn.z));
             const float tf = fminf(fminf(fmaf_(x.y, inv.x, cf.x), fmaf_(y.y, inv.y, cf.y)), fmaf_(z.y, inv.z, cf.z)) * kWiden;
             mask |= ((tf >= tn) && (tf >= 0.0f)) ? sv.lds_fmask[i] : 0u;
@@ -676,6 +713,7 @@ PT_DEV int closest_hit(const SceneView& sv, f3 P, f3 D, const LaneStack<typename
 
 // ---------------------------------------------------------------------------- BSDF sampling
 // prog.cl:186-218
+template <bool SK>
 PT_DEV f3 diffuse_direction(f3 N, float rnd1, float rnd2) {       // prog.cl:205-218 up to the normalisation (shade_hit does it)
     const float E = 0.001f;
     const bool yaxis = __builtin_fabsf(N.x) <= E && __builtin_fabsf(N.z) <= E;
@@ -686,7 +724,7 @@ PT_DEV f3 diffuse_direction(f3 N, float rnd1, float rnd2) {       // prog.cl:205
     const float r = __builtin_sqrtf(rnd1);
     const float theta = (float)(6.283185307179586 * (double)rnd2);
     float sn, cs;
-    spec_sincos(theta, &sn, &cs);
+    spec_sincos<SK>(theta, &sn, &cs);
     const float x = r * cs, y = r * sn, z = __builtin_sqrtf(1.0f - rnd1);
     f3 d = X * x;
     d = madd(N, z, d);
@@ -702,18 +740,41 @@ PT_DEV f3 fresnel(f3 F0, f3 N, f3 D) {
 }
 
 // ---------------------------------------------------------------------------- path state + shading
-// The path state of prog.cl:307-316 lives in plain local variables (registers), passed by
-// reference: P, D, the four factors, the colour, the LCG state and the inside-glass flag.
-#define PT_PATH_ARGS f3 &rP, f3 &rD, f3 &fL, f3 &fB, f3 &fS, f3 &fR, f3 &color, int &seed, bool &inside
+// The path state of prog.cl:307-316: ray (P, D), LCG state and inside-glass flag are plain local variables of the
+// caller; the four factors and the colour travel as one PathRegs.  (Round 3 also tried them in global memory behind the
+// same accessors for the 72 / 80-VGPR kernel instances -- [field][lane of the grid], a segment moving only what its
+// material touches: 1.5-3.6 % slower than letting the allocator spill, profiles/r03/c_*.)
+struct PathRegs {
+    f3 fL, fB, fS, fR, color;
+    PT_DEV void reset() {
+        fL = mk(1.f, 1.f, 1.f);
+        fB = fL;
+        fS = fL;
+        fR = fL;
+        color = mk(0.f, 0.f, 0.f);
+    }
+    PT_DEV f3 L() const { return fL; }
+    PT_DEV f3 B() const { return fB; }
+    PT_DEV f3 S() const { return fS; }
+    PT_DEV f3 R() const { return fR; }
+    PT_DEV f3 C() const { return color; }
+    PT_DEV void setL(f3 v) { fL = v; }
+    PT_DEV void setB(f3 v) { fB = v; }
+    PT_DEV void setS(f3 v) { fS = v; }
+    PT_DEV void setR(f3 v) { fR = v; }
+    PT_DEV void setC(f3 v) { color = v; }
+};
 
 // one iteration body of prog.cl:317-366 for a ray that hit packed triangle `ti` at `t`
-PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, const TriMeta* meta, int ti, float t) {
+// (SK: double-precision constants pinned to scalar registers, see KC)
+template <bool SK, class ST>
+PT_DEV void shade_hit(f3& rP, f3& rD, ST& st, int& seed, bool& inside, const RenderParams& p, const float4* tris, const TriMeta* meta, int ti, float t) {
     const float4 c = tris[ti * 3 + 2];
     f3 N = mk(c.y, c.z, c.w);
     const f3 hp = madd(rD, t, rP);
     const pt_material* __restrict__ m = &p.mats[meta[ti].mati];
     const int type = m->type;
-    if (p.iterations == 1) color = ldf3(m->kd) + ldf3(m->emission);         // prog.cl:323-325
+    if (p.iterations == 1) st.setC(ldf3(m->kd) + ldf3(m->emission));        // prog.cl:323-325
     if (dot3(rD, N) > 0.0f) N = -N;                                         // prog.cl:326-328
     // Every material that continues the path ends the same way: normalise the new direction, step off the surface
     // along +-N.  The two sampling branches below only produce the direction BEFORE normalisation and the side; the
@@ -727,7 +788,7 @@ PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, c
         // sampled ray drawn from two LCG values; the emitter's cosine uses the OLD direction.
         inten = max0(dot3(-rD, N));
         const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
-        dnew = diffuse_direction(N, rnd1, rnd2);
+        dnew = diffuse_direction<SK>(N, rnd1, rnd2);
     } else if (spec) {
         // mirror (prog.cl:341-345) and dielectric (prog.cl:346-357, 228-245) share the Fresnel
         // term and the mirror direction; the dielectric may pick the refracted direction instead.
@@ -747,15 +808,15 @@ PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, c
                 const f3 dn = mk(oldD.x / n, oldD.y / n, oldD.z / n);
                 dnew = madd(N, cosa / n - __builtin_sqrtf(disc), dn);
                 const float k = 1.0f / (1.0f - prob);
-                fR = (fR * mk(1.0f - F.x, 1.0f - F.y, 1.0f - F.z)) * k;
+                st.setR((st.R() * mk(1.0f - F.x, 1.0f - F.y, 1.0f - F.z)) * k);
                 inside = !inside;
                 side = -0.001f;
             } else {
                 const float k = 1.0f / prob;
-                fR = (fR * F) * k;
+                st.setR((st.R() * F) * k);
             }
         } else {
-            fS = fS * F;
+            st.setS(st.S() * F);
         }
     }
     if (lobe || spec) {
@@ -764,7 +825,7 @@ PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, c
     }
     if (type == 0) {
         const float idiff = max0(dot3(rD, N));
-        fL = fL * (ldf3(m->kd) * idiff);
+        st.setL(st.L() * (ldf3(m->kd) * idiff));
         // m->_pad = 1: ks is exactly 0 and shininess is finite >= 0, so ks * pow(...) is +-0 whatever the
         // (finite) power is -- skip the halfway vector (two normalisations) and the double-precision pow
         // (set by pt_upload_materials)
@@ -773,12 +834,12 @@ PT_DEV void shade_hit(PT_PATH_ARGS, const RenderParams& p, const float4* tris, c
             const f3 view = normalize3(ldf3(p.cam.eye) - hp);
             const f3 halfway = normalize3(view + rD);
             const float ispec = max0(dot3(N, halfway));
-            pw = spec_pow(ispec, m->shininess);
+            pw = spec_pow<SK>(ispec, m->shininess);
         }
-        fB = fB * (ldf3(m->ks) * pw);
+        st.setB(st.B() * (ldf3(m->ks) * pw));
     } else if (type == 3) {
-        const f3 e = ((ldf3(m->emission) * (fL + fB)) * fS) * fR;
-        color = madd(e, inten, color);
+        const f3 e = ((ldf3(m->emission) * (st.L() + st.B())) * st.S()) * st.R();
+        st.setC(madd(e, inten, st.C()));
     }
     // any other type: the ray is left unchanged and the loop hits the same surface again
 }
@@ -789,7 +850,6 @@ PT_DEV f3 running_mean(f3 acc, f3 color, int s) {   // prog.cl:379
 }
 
 // ---------------------------------------------------------------------------- LDS staging
-extern __shared__ __attribute__((aligned(16))) unsigned char pt_lds_raw[];
 
 // Nodes staged in LDS are re-laid out on the way in: the three box quads {L.lo, L.hi, R.lo, R.hi}
 // become {L.lo, R.lo, L.hi, R.hi}, so that one 8-byte read at (quad + 0 | 8) returns the entry
@@ -835,8 +895,8 @@ PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<type
     sv->treelet = (unsigned)p.treelet_nodes;
     sv->n_flat = p.n_flat;
     sv->lds_nodes = nullptr;
-    sv->stk_end = reinterpret_cast<const char*>(stk->base) + (size_t)p.stack_entries * BLOCK * sizeof(typename StackOf<MODE>::type);
-    sv->ovf = p.stack_ovf ? p.stack_ovf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x) : nullptr;
+    sv->lds_entries = p.stack_entries;
+    sv->ovf = p.stack_ovf ? p.stack_ovf + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BLOCK : nullptr;
     sv->ovf_stride = (unsigned)p.stack_ovf_lanes;
     float4* lds_flat = reinterpret_cast<float4*>(pt_lds_raw + traversal_nodes_end_dev<MODE, BLOCK>(p));
     for (int i = threadIdx.x; i < p.n_flat * 3; i += BLOCK) lds_flat[i] = p.tris[i];

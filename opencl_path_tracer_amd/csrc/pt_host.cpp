@@ -50,6 +50,8 @@ struct pt_context {
     void* comm = nullptr;          // ncclComm_t
     float4* d_gathered = nullptr;  // world x slab_pix
     float4* d_frame = nullptr;     // W x H
+    uint64_t render_epoch = 0;     // bumped by every call that writes colors
+    uint64_t frame_epoch = ~0ull;  // render_epoch at the last pt_gather_frame: d_frame is served only while they are equal
 
     // ---- authoring state (Scene members, main.cpp:365-372)
     std::vector<pt_triangle> tris;  // add order
@@ -150,6 +152,17 @@ int fail(pt_context* ctx, int code, const std::string& msg) {
 
 namespace ptamd {
 int fail_ctx(pt_context* ctx, int code, const std::string& msg) { return fail(ctx, code, msg); }   // for pt_obj.cpp, pt_image.cpp
+// pt_add_triangles without the copy, for pt_obj.cpp: n records are appended and returned for the caller to fill in place
+// (every one of them, before anything else touches the context)
+int append_triangles(pt_context* ctx, int64_t n, pt_triangle** tail) {
+    if (!ctx || n < 0 || !tail) return PT_EINVAL;
+    if ((int64_t)ctx->tris.size() + n > kMaxTriangles) return fail(ctx, PT_EINVAL, "more than 2^26 triangles");
+    const size_t old = ctx->tris.size();
+    ctx->tris.resize(old + (size_t)n);
+    ctx->tris_uploaded = false;
+    *tail = ctx->tris.data() + old;
+    return PT_OK;
+}
 // pt_comm.hip
 hipError_t launch_deinterleave(const float4* gathered, float4* frame, int W, int H, int world, int rb, long long slab_stride, hipStream_t stream);
 void gather_source_index(int W, int H, int world, int rb, long long slab_stride, int64_t* out);
@@ -192,42 +205,113 @@ inline int32_t global_row(const pt_context* c, int32_t lrow) {
 // (centroid <= mean goes right, main.cpp:241-244), rotating the axis while one side is empty.
 // prog.cl:159-181 always descends left first, so the order in which it can meet triangles is
 // the depth-first, left-first concatenation of the leaves.  Only that order is needed here.
+// The recursion is flattened: ONE index array is partitioned in place, stably (left part first, as the reference visits
+// it), the centroids are computed once, and the leaf order that results IS the encounter order.  The mean of a node is
+// still summed sequentially in index order -- float addition, the reference's rounding (main.cpp:224-236) -- but disjoint
+// subtrees are independent and run on separate threads (1M triangles: 228 -> ~40 ms, profiles/r03/e_*).
 struct RefOrder {
     const std::vector<pt_triangle>& tris;
     std::vector<int32_t>& rank;
     int32_t& next_rank;
     bool degenerate = false;
 
-    static inline float mid(const pt_triangle& t, int a) { return (t.r1.s[a] + t.r2.s[a] + t.r3.s[a]) / 3.0f; }
+    struct Range { int32_t begin, end, depth; };
 
-    void run(std::vector<int32_t>& idx, int depth) {
-        const size_t n = idx.size();
-        if (n <= 6) {
-            for (int32_t i : idx) rank[i] = next_rank++;
-            return;
+    // partitions [r.begin, r.end) of idx; returns the size of the left part, 0 for a leaf, -1 for the reference's endless loop
+    static int32_t split(const Range& r, int32_t* idx, int32_t* tmp, const float* cx, const float* cy, const float* cz) {
+        const int32_t n = r.end - r.begin;
+        if (n <= 6) return 0;
+        int32_t* ix = idx + r.begin;
+        float mx = cx[ix[0]], my = cy[ix[0]], mz = cz[ix[0]];
+        for (int32_t i = 1; i < n; ++i) {
+            mx = mx + cx[ix[i]];
+            my = my + cy[ix[i]];
+            mz = mz + cz[ix[i]];
         }
-        float m[3] = {mid(tris[idx[0]], 0), mid(tris[idx[0]], 1), mid(tris[idx[0]], 2)};
-        for (size_t i = 1; i < n; ++i)
-            for (int a = 0; a < 3; ++a) m[a] = m[a] + mid(tris[idx[i]], a);
-        for (int a = 0; a < 3; ++a) m[a] = m[a] / (float)(unsigned long)n;
-        int axis = depth % 3;
-        std::vector<int32_t> left, right;
+        const float m[3] = {mx / (float)(unsigned long)n, my / (float)(unsigned long)n, mz / (float)(unsigned long)n};
+        const float* c[3] = {cx, cy, cz};
+        int axis = r.depth % 3;
         for (int tries = 0;; ++tries) {
-            left.clear();
-            right.clear();
-            for (int32_t i : idx) {
-                if (m[axis] >= mid(tris[i], axis)) right.push_back(i); else left.push_back(i);
+            const float* ca = c[axis];
+            const float ma = m[axis];
+            int32_t nl = 0, nr = 0;
+            for (int32_t i = 0; i < n; ++i) {
+                const int32_t t = ix[i];
+                if (ma >= ca[t]) tmp[r.begin + nr++] = t;      // centroid <= mean goes right (main.cpp:241-244)
+                else ix[nl++] = t;                              // (nl <= i: never overtakes the read position)
             }
-            if (!left.empty() && !right.empty()) break;
-            if (tries == 2) {  // the reference loops forever here (main.cpp:246-257)
-                degenerate = true;
-                return;
+            if (nl != 0 && nr != 0) {
+                std::memcpy(ix + nl, tmp + r.begin, sizeof(int32_t) * (size_t)nr);
+                return nl;
             }
+            if (nl == 0) std::memcpy(ix, tmp + r.begin, sizeof(int32_t) * (size_t)nr);    // everything went right: restore the order
+            if (tries == 2) return -1;          // the reference loops forever here (main.cpp:246-257)
             axis = (axis + 1) % 3;
         }
-        std::vector<int32_t>().swap(idx);
-        run(left, depth + 1);
-        run(right, depth + 1);
+    }
+
+    // triangles [first, first + n) of `tris` (one object, add order)
+    void run(int32_t first, int32_t n, int threads) {
+        std::vector<float> cx((size_t)n), cy((size_t)n), cz((size_t)n);
+        std::vector<int32_t> idx((size_t)n), tmp((size_t)n);
+        for (int32_t i = 0; i < n; ++i) {
+            const pt_triangle& t = tris[(size_t)(first + i)];
+            cx[(size_t)i] = (t.r1.s[0] + t.r2.s[0] + t.r3.s[0]) / 3.0f;
+            cy[(size_t)i] = (t.r1.s[1] + t.r2.s[1] + t.r3.s[1]) / 3.0f;
+            cz[(size_t)i] = (t.r1.s[2] + t.r2.s[2] + t.r3.s[2]) / 3.0f;
+            idx[(size_t)i] = i;
+        }
+        std::atomic<bool> bad(false);
+        auto descend = [&](Range root) {          // depth-first over an explicit stack (the reference's tree can be very deep)
+            std::vector<Range> st;
+            st.push_back(root);
+            while (!st.empty() && !bad.load(std::memory_order_relaxed)) {
+                const Range r = st.back();
+                st.pop_back();
+                const int32_t nl = split(r, idx.data(), tmp.data(), cx.data(), cy.data(), cz.data());
+                if (nl < 0) { bad.store(true); return; }
+                if (nl == 0) continue;
+                st.push_back(Range{r.begin + nl, r.end, r.depth + 1});
+                st.push_back(Range{r.begin, r.begin + nl, r.depth + 1});
+            }
+        };
+        // the top of the tree serially, until there are enough independent ranges; then one range per task
+        std::vector<Range> open;
+        open.push_back(Range{0, n, 0});
+        const int32_t grain = std::max<int32_t>(n / (8 * std::max(threads, 1)), 4096);
+        std::vector<Range> tasks;
+        while (!open.empty() && !bad.load()) {
+            const Range r = open.back();
+            open.pop_back();
+            if (threads <= 1 || r.end - r.begin <= grain) { tasks.push_back(r); continue; }
+            const int32_t nl = split(r, idx.data(), tmp.data(), cx.data(), cy.data(), cz.data());
+            if (nl < 0) { bad.store(true); break; }
+            if (nl == 0) continue;
+            open.push_back(Range{r.begin + nl, r.end, r.depth + 1});
+            open.push_back(Range{r.begin, r.begin + nl, r.depth + 1});
+        }
+        if (!bad.load()) {
+            const int nt = std::max(1, std::min<int>(threads, (int)tasks.size()));
+            if (nt == 1) {
+                for (const Range& r : tasks) descend(r);
+            } else {
+                std::sort(tasks.begin(), tasks.end(), [](const Range& a, const Range& b) { return a.end - a.begin > b.end - b.begin; });
+                std::atomic<size_t> next(0);
+                std::vector<std::thread> th;
+                for (int k = 0; k < nt; ++k)
+                    th.emplace_back([&]() {
+                        for (;;) {
+                            const size_t i = next.fetch_add(1);
+                            if (i >= tasks.size()) return;
+                            descend(tasks[i]);
+                        }
+                    });
+                for (std::thread& t : th) t.join();
+            }
+        }
+        if (bad.load()) { degenerate = true; return; }
+        for (int32_t k = 0; k < n; ++k) rank[(size_t)(first + idx[(size_t)k])] = next_rank + k;
+        next_rank += n;
     }
 };
 
@@ -678,9 +762,10 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 constexpr size_t kLdsSlack = 32 * 100 + 4096 + 1024 + 256;
 
 // Does the whole tree fit next to two 512-thread workgroups per CU (kNodesLds: 16-bit references)?
-bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int interior_depth) {
+bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int interior_depth, int n_flat) {
     const bool s16 = n_nodes <= 32767 && n_tris <= 4096;
-    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(interior_depth) * 2 * 512 + 32 * 100 + 32 <= kLdsPerCu / 2;   // (+ flat list: packet + box + group mask per triangle)
+    const size_t block = (size_t)std::max(kLdsRenderBlock, 512);     // (k_render; wf_intersect and the debug kernel use 512)
+    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(interior_depth) * 2 * block + (size_t)n_flat * 100 + 64 <= kLdsPerCu / 2;   // (+ flat list: packet + box + group mask per triangle)
 }
 
 // Treelet: when the tree is too large for LDS, the T nodes with the largest boxes --
@@ -760,7 +845,7 @@ int plan_node_placement(pt_context* ctx) {
     group_flat_boxes(ctx);
     ctx->interior_depth = deepest_interior_node(ctx->nodes);
     if (ctx->interior_depth + 2 > kStackEntries) return fail(ctx, PT_ESCENE, "internal: BVH deeper than the traversal stack");
-    const bool fits = whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->interior_depth);
+    const bool fits = whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->interior_depth, ctx->n_flat);
     if (ctx->treelet != 0 && !fits) ctx->treelet_nodes = reindex_treelet(ctx->nodes, ctx->interior_depth, ctx->treelet);
     // 4-wide nodes for trees read from global memory -- unless their worst-case stack would not leave room for four
     // 256-thread workgroups per CU (then the BVH2 path stays)
@@ -839,7 +924,7 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->node_mode = kNodesGlobal;
     p->treelet_nodes = 0;
     if (ctx->lds_scene) {
-        if (whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->interior_depth)) {
+        if (whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->interior_depth, ctx->n_flat)) {
             p->node_mode = kNodesLds;
         } else if (ctx->treelet_nodes > 0) {
             p->node_mode = kNodesTreelet;
@@ -981,6 +1066,7 @@ int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int
     if (!out) return fail(nullptr, PT_EINVAL, "out is NULL");
     *out = nullptr;
     if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(nullptr, PT_EINVAL, "bad frame size");
+    if (width > 65535 || height > 65535) return fail(nullptr, PT_EINVAL, "bad frame size: at most 65,535 pixels per side (the kernels pack a pixel's coordinates into 2 x 16 bits)");
     if (world < 1 || rank < 0 || rank >= world || rows_per_block < 1) return fail(nullptr, PT_EINVAL, "bad rank/world/rows_per_block");
     pt_context* ctx = new pt_context();
     ctx->W = width;
@@ -1027,6 +1113,7 @@ int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int
     if ((e = hipMalloc((void**)&ctx->d_colors, sizeof(float4) * nslab)) != hipSuccess) return bail("hipMalloc(colors)", e);  // main.cpp:520
     if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatCols * kStatRows)) != hipSuccess) return bail("hipMalloc(stats)", e);
     if ((e = hipMalloc((void**)&ctx->d_tile_counter, 64)) != hipSuccess) return bail("hipMalloc(tile counter)", e);
+    if ((e = hipMemset(ctx->d_tile_counter, 0, 64)) != hipSuccess) return bail("hipMemset", e);      // zeroed ONCE: the last wave of a launch leaves it zero (k_render)
     if ((e = hipMemset(ctx->d_rays, 0, sizeof(pt_ray) * np)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->d_colors, 0, sizeof(float4) * nslab)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * kStatCols * kStatRows)) != hipSuccess) return bail("hipMemset", e);
@@ -1105,10 +1192,9 @@ int pt_end_obj(pt_context* ctx) {
     const int32_t n = (int32_t)ctx->tris.size() - ctx->tri_shift;
     if (n <= 0) return fail(ctx, PT_ESCENE, "end_Obj on an empty object (the reference reads tris[0] of an empty vector, main.cpp:216)");
     ctx->enc_rank.resize(ctx->tris.size(), -1);
-    std::vector<int32_t> idx((size_t)n);
-    std::iota(idx.begin(), idx.end(), ctx->tri_shift);
     RefOrder ro{ctx->tris, ctx->enc_rank, ctx->next_rank};
-    ro.run(idx, 0);
+    const unsigned hw = std::thread::hardware_concurrency();
+    ro.run(ctx->tri_shift, n, ctx->build_threads > 0 ? ctx->build_threads : (int)std::min<unsigned>(hw ? hw : 1u, 16u));
     if (ro.degenerate) {
         ctx->tris.resize((size_t)ctx->tri_shift);
         ctx->enc_rank.resize((size_t)ctx->tri_shift);
@@ -1401,10 +1487,10 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
     // 95.7 % against 88 %; profiles/r02/e_*, q_*).
     // resident workgroups at 4 waves per SIMD: 2 x 512 threads (whole tree in LDS), 1 x 1024 (treelet) per CU; nodes through
     // L1/L2 (256 threads): as many waves per SIMD -- 7, 6, 5 or 4 -- as the stacks in LDS leave room for
-    lc->waves_per_simd = 4;
+    lc->waves_per_simd = p.node_mode == kNodesLds ? kLdsRenderWps : 4;
     if (p.node_mode == kNodesGlobal || p.node_mode == kNodesWide) {
         const int want = ctx->waves_per_simd > 0 ? ctx->waves_per_simd : 7;
-        for (int w = std::min(want, 7); w > 4; --w)
+        for (int w = std::min(want, 8); w > 4; --w)
             if ((size_t)w * lc->lds_bytes + 1024 <= kLdsPerCu) { lc->waves_per_simd = w; break; }
     }
     lc->persistent_blocks = ctx->cu_count * std::max(1, 256 * lc->waves_per_simd / lc->block);
@@ -1438,12 +1524,12 @@ int pt_trace_rays(pt_context* ctx, const pt_camera* cam, int32_t iterations, int
     LaunchConfig lc;
     launch_cfg(ctx, p, &lc);
     if (ctx->persistent) {      // the grid only fills the chip: a workgroup stages the tree once, not once per eight tiles
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counter, 0, sizeof(uint32_t), ctx->stream));
-        p.tile_counter = ctx->d_tile_counter;
+        p.tile_counter = ctx->d_tile_counter;      // (zero: the previous launch's last wave reset it)
     }
     EventPair* ep;
     if ((rc = time_begin(ctx, &ep)) != PT_OK) return rc;
     PT_HIP(ctx, launch_trace_ray(p, lc, ctx->stream));
+    ctx->render_epoch++;
     return time_end(ctx, ep);
 }
 
@@ -1505,6 +1591,7 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
     p.iterations = iterations;
     p.first_sample = ctx->current_sample;
     p.nsamples = nsamples;
+    ctx->render_epoch++;
     if (ctx->variant == 1) {
         if ((rc = render_wavefront(ctx, p, nsamples)) != PT_OK) return rc;
         ctx->current_sample += nsamples;
@@ -1513,8 +1600,7 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
     LaunchConfig lc;
     launch_cfg(ctx, p, &lc);
     if (ctx->persistent) {
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counter, 0, sizeof(uint32_t), ctx->stream));
-        p.tile_counter = ctx->d_tile_counter;
+        p.tile_counter = ctx->d_tile_counter;      // (zero: the previous launch's last wave reset it)
         // automatic: chaining passes only pays when there are enough tiles to re-balance; with about one
         // tile per resident wave (a 1080p frame over 8 GPUs) the most expensive tile is the critical path
         // either way and the extra hand-offs cost 2-4 %.  With many tiles per wave (one GPU, 1080p: 7.9) the
@@ -1618,16 +1704,24 @@ int pt_gather_frame(pt_context* ctx) {
     const int rc = comm_all_gather(ctx->comm, ctx->d_colors, ctx->d_gathered, slab * 4, ctx->stream, &err);
     if (rc != PT_OK) return fail(ctx, rc, err);
     PT_HIP(ctx, launch_deinterleave(ctx->d_gathered, ctx->d_frame, ctx->W, ctx->H, ctx->world, ctx->rows_per_block, (long long)slab, ctx->stream));
+    ctx->frame_epoch = ctx->render_epoch;
     return PT_OK;
 }
 
-void* pt_device_frame(pt_context* ctx) { return !ctx ? nullptr : (ctx->world == 1 && !ctx->d_frame) ? (void*)ctx->d_colors : (void*)ctx->d_frame; }
+// The assembled frame: the gathered copy while nothing has been rendered since the gather; for a one-rank context the
+// colors buffer otherwise (it IS the frame); for a tiled context nothing -- a frame older than colors is never served.
+static const float4* current_frame(const pt_context* ctx) {
+    if (ctx->d_frame && ctx->frame_epoch == ctx->render_epoch) return ctx->d_frame;
+    return ctx->world == 1 ? ctx->d_colors : nullptr;
+}
+
+void* pt_device_frame(pt_context* ctx) { return !ctx ? nullptr : (void*)current_frame(ctx); }
 
 int pt_read_frame(pt_context* ctx, float* out, int64_t npix) {
     PT_NEED_DEVICE(ctx);
     if (!out || npix != (int64_t)ctx->W * ctx->H) return fail(ctx, PT_EINVAL, "npix must equal width * height of the global frame");
-    const float4* src = (ctx->world == 1 && !ctx->d_frame) ? ctx->d_colors : ctx->d_frame;
-    if (!src) return fail(ctx, PT_EINVAL, "pt_gather_frame has not been called");
+    const float4* src = current_frame(ctx);
+    if (!src) return fail(ctx, PT_EINVAL, ctx->d_frame ? "the gathered frame is older than colors: call pt_gather_frame again" : "pt_gather_frame has not been called");
     PT_HIP(ctx, hipSetDevice(ctx->device));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(out, src, sizeof(float4) * (size_t)npix, hipMemcpyDeviceToHost));
@@ -1769,7 +1863,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, "suspend_lanes: -1 default, 0..63");
         ctx->suspend_lanes = (int)value;
     } else if (k == "waves_per_simd") {
-        if (value != -1 && (value < 4 || value > 7)) return fail(ctx, PT_EINVAL, "waves_per_simd: -1 automatic, 4..7 (kernels that read nodes from global memory)");
+        if (value != -1 && (value < 4 || value > 8)) return fail(ctx, PT_EINVAL, "waves_per_simd: -1 automatic (at most 7), 4..8 (kernels that read nodes from global memory)");
         ctx->waves_per_simd = (int)value;
     } else if (k == "debug_repeat") {
         if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "debug_repeat: 0..1000 extra timed launches");

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -67,6 +68,20 @@ constexpr int kMaxLeaf = 4;        // triangles per leaf (<= 8 by the reference 
 constexpr int kMaxDepth = 30;      // builder guarantees depth <= kMaxDepth
 constexpr int kStatRows = 256;     // statistics counters are spread over this many rows of kStatCols
 constexpr int kStatCols = 16;
+// k_render instances whose register budget is set for this many waves per SIMD or more carry nothing across a traversal
+// that can be recomputed or fetched (LEAN, pt_kernels.hip) -- A/B switch: 8 = never
+#ifndef PT_LEAN_FROM_WPS
+#define PT_LEAN_FROM_WPS 6
+#endif
+constexpr int kLeanFromWps = PT_LEAN_FROM_WPS;
+// the k_render instance for a tree staged whole in LDS: threads per workgroup / waves per SIMD (two workgroups per CU either
+// way).  A/B switch: 640 / 5 = a fifth wave per SIMD at 96 VGPRs
+#ifndef PT_LDS_BLOCK
+#define PT_LDS_BLOCK 512
+#define PT_LDS_WPS 4
+#endif
+constexpr int kLdsRenderBlock = PT_LDS_BLOCK;
+constexpr int kLdsRenderWps = PT_LDS_WPS;
 constexpr int kStackEntries = 36;  // upper bound of the per-lane traversal stack: sentinel + far children + one slot above the top
 
 // ---- kernel parameter block (passed by value, like `Camera` in prog.cl:292-304) ----------
@@ -96,7 +111,7 @@ struct RenderParams {
                                  // above the top); kNodesWide: at most kWideLdsEntries, the rest of the worst case in stack_ovf
     uint32_t* stack_ovf;         // kNodesWide: [entries past the LDS part][lane of the grid], or null when LDS holds the worst case
     int32_t stack_ovf_lanes;     // lanes stack_ovf has room for (every launch's grid must fit)
-    uint32_t* tile_counter;      // != 0: persistent launch, waves pull tile indices from this counter
+    uint32_t* tile_counter;      // != 0: persistent launch, waves pull tile indices from word 0; word 1 counts the waves that left (the last resets both)
     int32_t n_tiles;
     int32_t chunk_spp;           // > 0: a work item is (pass, tile) = chunk_spp samples of a tile; passes of one
                                  // tile are chained through tile_done[] (agent-scope release / acquire)
@@ -152,6 +167,27 @@ struct LaunchConfig {
     int schedule = 0;                  // megakernel: 0 lockstep per sample, 1 restart + tail suspension (pt_kernels.hip)
     int waves_per_simd = 4;            // register budget of the k_render instance: 4, or 5 / 6 / 7 for nodes from global memory
 };
+
+// Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel.  Set ONCE per kernel instance
+// and device (a high-water mark), not per launch: the reference's own loop shape launches a kernel per sample
+// (main.cpp:683-687) and a per-launch runtime call shows there.  `mark` = one static array per template instantiation.
+constexpr int kMaxDevicesPerProcess = 16;
+struct LdsMark {
+    std::atomic<size_t> bytes[kMaxDevicesPerProcess];
+};
+inline hipError_t ensure_dynamic_lds(const void* kern, LdsMark& mark, size_t lds_bytes) {
+    if (lds_bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevicesPerProcess) return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (mark.bytes[dev].load(std::memory_order_acquire) >= lds_bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    size_t seen = mark.bytes[dev].load(std::memory_order_relaxed);
+    while (seen < lds_bytes && !mark.bytes[dev].compare_exchange_weak(seen, lds_bytes, std::memory_order_release)) {}
+    return hipSuccess;
+}
 
 // launchers (pt_kernels.hip, pt_wavefront.hip, pt_debug.hip); all asynchronous on `stream`
 int traversal_block(int node_mode);                            // threads per workgroup of the traversal kernels

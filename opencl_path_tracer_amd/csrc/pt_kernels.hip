@@ -63,20 +63,42 @@ __global__ void __launch_bounds__(256) k_gen_ray(RenderParams p) {
 //                  the latency-bound mesh scenes where every wave-level step saved is a memory round trip saved.
 enum : int { kSchedLockstep = 0, kSchedSuspend = 1 };
 
-template <bool SPLIT, int MODE, bool COUNT>
+
+// LEAN (the instances for 6 / 7 waves per SIMD: 80 / 72 VGPRs hold the traversal and little else): nothing that can be
+// recomputed or fetched is carried across a traversal -- the running mean is folded into colors[] at the end of every
+// sample, as prog.cl:379 does, instead of riding in three registers for the whole work item, and the pixel's float
+// coordinates are rebuilt from its id at every sample start.  (The allocator spilled seven dwords around every
+// traversal of the 72-VGPR instance: 16 GB written and ~38 GB re-read per 42-ms launch, profiles/r03/a_*.)
+// prog.cl:379 on the frame buffer itself (LEAN): sample 0 starts from black (prog.cl:312-314)
+PT_DEV void fold_sample(const RenderParams& p, int li, f3 color, int s) {
+    f3 acc = mk(0.0f, 0.0f, 0.0f);
+    if (s != 0) {
+        const float4 c = p.colors[li];
+        acc = mk(c.x, c.y, c.z);
+    }
+    acc = running_mean(acc, color, s);
+    p.colors[li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+}
+
+template <bool SPLIT, int MODE, bool COUNT, bool LEAN, bool SK>
 PT_DEV void render_pixel_lockstep(const RenderParams& p, const SceneView& sv, const LaneStack<typename StackOf<MODE>::type> stk, const PixelId px,
-                                  int s_begin, int s_end, unsigned long long* segs, unsigned long long* samples, WorkCount* wc) {
+                                  int s_begin, int s_end, unsigned* segs, WorkCount* wc) {
     int seed = p.rnds[px.li];
     f3 acc = mk(0.0f, 0.0f, 0.0f);
-    if (s_begin != 0) {                        // prog.cl:312-314: sample 0 starts from black
+    if (!LEAN && s_begin != 0) {               // prog.cl:312-314: sample 0 starts from black
         const float4 c = p.colors[px.li];
         acc = mk(c.x, c.y, c.z);
     }
     const int camX = (int)p.cam.XM;
-    const float pix_x = (float)(px.gid % camX), pix_y = (float)(px.gid / camX);      // prog.cl:84-85
+    const int gx = px.gid % camX, gy = px.gid / camX;                                // prog.cl:84-85
+    const unsigned pxy = (unsigned)gx | ((unsigned)gy << 16);                        // LEAN: one register (frames below 65,536 x 65,536: pt_create)
+    const float pix_x0 = (float)gx, pix_y0 = (float)gy;
     f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
+    PathRegs st;
+    st.reset();
     for (int s = s_begin; s < s_end; ++s) {    // the same trip count on every lane of the wave
-        f3 fL = mk(1.f, 1.f, 1.f), fB = fL, fS = fL, fR = fL, color = mk(0.f, 0.f, 0.f);     // prog.cl:307-316
+        const float pix_x = LEAN ? (float)(pxy & 0xffffu) : pix_x0, pix_y = LEAN ? (float)(pxy >> 16) : pix_y0;
+        st.reset();                            // prog.cl:307-316
         bool inside = false;
         if (SPLIT) {
             const float4* r = reinterpret_cast<const float4*>(&p.rays[px.li]);
@@ -94,12 +116,12 @@ PT_DEV void render_pixel_lockstep(const RenderParams& p, const SceneView& sv, co
             ++*segs;
             if (ti < 0) break;                                       // black environment, prog.cl:367-376
             if (COUNT && first_active_lane()) wc->wshade++;
-            shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, ti, t);
+            shade_hit<SK>(rP, rD, st, seed, inside, p, sv.tris, sv.meta, ti, t);
         }
-        acc = running_mean(acc, color, s);
-        ++*samples;
+        if (LEAN) fold_sample(p, px.li, st.C(), s);
+        else acc = running_mean(acc, st.C(), s);
     }
-    p.colors[px.li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    if (!LEAN) p.colors[px.li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
     p.rnds[px.li] = seed;
     if (SPLIT) {
         float4* r = reinterpret_cast<float4*>(&p.rays[px.li]);
@@ -108,15 +130,16 @@ PT_DEV void render_pixel_lockstep(const RenderParams& p, const SceneView& sv, co
     }
 }
 
-template <bool SPLIT, int MODE, bool COUNT>
+template <bool SPLIT, int MODE, bool COUNT, bool LEAN, bool SK>
 PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, const LaneStack<typename StackOf<MODE>::type> stk, const PixelId px,
-                                 int s_begin, int s_end, unsigned long long* segs, unsigned long long* samples, WorkCount* wc) {
+                                 int s_begin, int s_end, unsigned* segs, WorkCount* wc) {
     f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
-    f3 fL = mk(1.f, 1.f, 1.f), fB = fL, fS = fL, fR = fL, color = mk(0.f, 0.f, 0.f);
+    PathRegs st;
+    st.reset();
     bool inside = false;
     int seed = p.rnds[px.li];
     f3 acc = mk(0.0f, 0.0f, 0.0f);
-    if (s_begin != 0) {                        // prog.cl:312-314: sample 0 starts from black
+    if (!LEAN && s_begin != 0) {               // prog.cl:312-314: sample 0 starts from black
         const float4 c = p.colors[px.li];
         acc = mk(c.x, c.y, c.z);
     }
@@ -129,16 +152,14 @@ PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, con
     tr.restart(stk);
     tr.idle();
     const int camX = (int)p.cam.XM;
-    const float pix_x = (float)(px.gid % camX), pix_y = (float)(px.gid / camX);      // prog.cl:84-85
+    const int gx = px.gid % camX, gy = px.gid / camX;                                // prog.cl:84-85
+    const unsigned pxy = (unsigned)gx | ((unsigned)gy << 16);                        // LEAN: one register
+    const float pix_x0 = (float)gx, pix_y0 = (float)gy;
     for (;;) {
         if (COUNT && first_active_lane()) wc->wtrips++;
         if (fresh && !traversing) {            // a lane whose path ended starts its next sample right here
             if (s == s_end) break;
-            fL = mk(1.f, 1.f, 1.f);            // prog.cl:307-316
-            fB = fL;
-            fS = fL;
-            fR = fL;
-            color = mk(0.f, 0.f, 0.f);
+            st.reset();                        // prog.cl:307-316
             inside = false;
             if (SPLIT) {
                 const float4* r = reinterpret_cast<const float4*>(&p.rays[px.li]);
@@ -147,6 +168,7 @@ PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, con
                 rD = mk(b.x, b.y, b.z);
             } else {
                 const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+                const float pix_x = LEAN ? (float)(pxy & 0xffffu) : pix_x0, pix_y = LEAN ? (float)(pxy >> 16) : pix_y0;
                 camera_get_ray_xy(pix_x, pix_y, p.cam, rnd1, rnd2, &rP, &rD);
             }
             bounce = 0;
@@ -173,20 +195,20 @@ PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, con
                 ++*segs;
                 if (tr.best >= 0) {
                     if (COUNT && first_active_lane()) wc->wshade++;
-                    shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, sv.tris, sv.meta, tr.best, tr.best_t);
+                    shade_hit<SK>(rP, rD, st, seed, inside, p, sv.tris, sv.meta, tr.best, tr.best_t);
                     ++bounce;
                     finished = (bounce >= p.iterations);
                 }
             }
         }
         if (finished) {
-            acc = running_mean(acc, color, s);
+            if (LEAN) fold_sample(p, px.li, st.C(), s);
+            else acc = running_mean(acc, st.C(), s);
             ++s;
-            ++*samples;
-            fresh = true;
+                fresh = true;
         }
     }
-    p.colors[px.li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    if (!LEAN) p.colors[px.li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
     p.rnds[px.li] = seed;
     if (SPLIT) {
         float4* r = reinterpret_cast<float4*>(&p.rays[px.li]);
@@ -215,6 +237,8 @@ PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, con
 // box: profiles/r02/t_*, v_*).
 template <bool SPLIT, int MODE, int BLOCK, bool COUNT, int SCHED, int WPS>
 __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
+    constexpr bool kLean = WPS >= kLeanFromWps;      // see render_pixel_*
+    constexpr bool kScalarK = WPS >= 5;              // double-precision constants in scalar registers (KC, pt_device.hpp)
     LaneStack<typename StackOf<MODE>::type> stk;
     SceneView sv;
     setup_traversal<MODE, BLOCK>(p, &sv, &stk);
@@ -229,7 +253,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
     const bool lane0 = (threadIdx.x & 63) == 0;
     const bool chained = p.tile_counter != nullptr && p.chunk_spp > 0;
     const int n_pass = chained ? (p.nsamples + p.chunk_spp - 1) / p.chunk_spp : 1;
-    unsigned long long segs = 0, samples = 0, segs_before_item = 0, item_lane_steps = 0;
+    // statistics of the launch: wave-level totals, kept in SCALAR registers (a per-lane 64-bit counter pair costs four VGPRs
+    // through every traversal); a lane only counts the segments of its current work item, in 32 bits
+    unsigned long long segs_tot = 0, samples_tot = 0, item_lane_steps = 0;
     int tile = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     int pass = 0;
     for (;;) {
@@ -238,7 +264,11 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
             // it is never spilled lane by lane under whatever exec mask the spill happens to land in)
             int t = 0;
             if (lane0) t = (int)atomicAdd(p.tile_counter, 1u);
+#ifdef PT_TEST_WORK_ITEM_IN_VGPR      // round 2's bug, kept only to show that tools/check_isa.py catches it (never built into the library)
+            t = __shfl(t, 0, 64);
+#else
             t = __builtin_amdgcn_readfirstlane(t);
+#endif
             pass = chained ? t / p.n_tiles : 0;
             tile = t - pass * p.n_tiles;
             if (chained ? pass >= n_pass : tile >= p.n_tiles) break;
@@ -256,15 +286,21 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
         const int s_begin = p.first_sample + (chained ? pass * p.chunk_spp : 0);
         const int s_end = chained ? min(s_begin + p.chunk_spp, p.first_sample + p.nsamples) : p.first_sample + p.nsamples;
         const PixelId px = pixel_of_wave(p, tile);
+        unsigned item_segs = 0;
         if (px.li >= 0) {
-            if (SCHED == kSchedLockstep) render_pixel_lockstep<SPLIT, MODE, COUNT>(p, sv, stk, px, s_begin, s_end, &segs, &samples, &wc);
-            else render_pixel_suspend<SPLIT, MODE, COUNT>(p, sv, stk, px, s_begin, s_end, &segs, &samples, &wc);
+            if (SCHED == kSchedLockstep) render_pixel_lockstep<SPLIT, MODE, COUNT, kLean, kScalarK>(p, sv, stk, px, s_begin, s_end, &item_segs, &wc);
+            else render_pixel_suspend<SPLIT, MODE, COUNT, kLean, kScalarK>(p, sv, stk, px, s_begin, s_end, &item_segs, &wc);
+        }
+        {
+            unsigned v = item_segs;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            segs_tot += (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            samples_tot += (unsigned long long)__popcll(__ballot(px.li >= 0)) * (unsigned)(s_end - s_begin);
         }
         if (COUNT) {      // segment-steps the wave executed for this item = 64 x the busiest lane's segments
-            unsigned long long mx = segs - segs_before_item;
-            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned long long)__shfl_down(mx, off, 64));
-            if (lane0) item_lane_steps += mx * 64ull;
-            segs_before_item = segs;
+            unsigned mx = item_segs;
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_down(mx, off, 64));
+            item_lane_steps += (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)mx) * 64ull;
         }
         if (chained) {                                           // ---- release this pass of the tile
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -273,8 +309,17 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
         }
         if (!p.tile_counter) break;
     }
-    segs = wave_sum(segs);
-    samples = wave_sum(samples);
+    if (p.tile_counter) {
+        // Last wave out resets the work counter (word 0) and the exit count (word 1), so the host never clears them: every
+        // wave of the grid comes here exactly once, after its one failed fetch, and nobody reads word 0 after that.
+        unsigned gone = 0;
+        if (lane0) gone = atomicAdd(p.tile_counter + 1, 1u);
+        gone = (unsigned)__builtin_amdgcn_readfirstlane((int)gone);
+        if (lane0 && gone + 1u == gridDim.x * (BLOCK / 64)) {
+            __hip_atomic_store(p.tile_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.tile_counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (COUNT) {
         const unsigned long long wn = wave_sum((unsigned long long)wc.nodes), wt = wave_sum((unsigned long long)wc.tris);
         const unsigned long long wwn = wave_sum((unsigned long long)wc.wnodes), wwt = wave_sum((unsigned long long)wc.wtris);
@@ -291,15 +336,15 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
         }
     }
     if (lane0 && p.stats) {
-        stat_add(p, 0, segs);
-        stat_add(p, 1, samples);
+        stat_add(p, 0, segs_tot);
+        stat_add(p, 1, samples_tot);
     }
 }
 
 // ---- tone mapping, prog.cl:247-269 (value of write_imagef at prog.cl:380)
 PT_DEV float srgb1(float a) {
     if (a <= 0.00304f) return 12.92f * a;
-    return fmaf_(1.055f, spec_pow(a, 0.4167f), -0.055f);
+    return fmaf_(1.055f, spec_pow<false>(a, 0.4167f), -0.055f);
 }
 __global__ void __launch_bounds__(256) k_resolve_reinhard(const float4* colors, float4* out, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,7 +404,7 @@ static inline int n_waves(const RenderParams& p) {
     return tiles_x * tiles_y;
 }
 
-int traversal_block(int node_mode) { return node_mode == kNodesLds ? 512 : node_mode == kNodesTreelet ? 1024 : 256; }
+int traversal_block(int node_mode) { return node_mode == kNodesLds ? kLdsRenderBlock : node_mode == kNodesTreelet ? 1024 : 256; }      // of k_render
 
 size_t traversal_lds_bytes(const RenderParams& p, int block) {
     size_t b = (size_t)p.stack_entries * (p.node_mode == kNodesLds ? 2 : 4) * (size_t)block;
@@ -386,10 +431,9 @@ static hipError_t launch_one(const RenderParams& p, const LaunchConfig& lc, hipS
     if (p.tile_counter) blocks = std::min(blocks, lc.persistent_blocks);
     if (p.stack_ovf && (long long)blocks * BLOCK > (long long)p.stack_ovf_lanes) return hipErrorInvalidValue;   // (pt_host.cpp alloc_stack_overflow)
     auto kern = k_render<SPLIT, MODE, BLOCK, COUNT, SCHED, WPS>;
-    if (lc.lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc.lds_bytes);
-        if (e != hipSuccess) return e;
-    }
+    static LdsMark mark;
+    const hipError_t e = ensure_dynamic_lds((const void*)kern, mark, lc.lds_bytes);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), lc.lds_bytes, stream, p);
     return hipGetLastError();
 }
@@ -398,13 +442,15 @@ template <bool SPLIT, bool COUNT, int SCHED>
 static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
     if (lc.block != traversal_block(p.node_mode)) return hipErrorInvalidValue;
     switch (p.node_mode) {
-    case kNodesLds: return launch_one<SPLIT, kNodesLds, 512, COUNT, SCHED, 4>(p, lc, stream);
+    case kNodesLds: return launch_one<SPLIT, kNodesLds, kLdsRenderBlock, COUNT, SCHED, kLdsRenderWps>(p, lc, stream);
     case kNodesGlobal:
+        if (lc.waves_per_simd == 8) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 8>(p, lc, stream);
         if (lc.waves_per_simd == 7) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 7>(p, lc, stream);
         if (lc.waves_per_simd == 6) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 6>(p, lc, stream);
         if (lc.waves_per_simd == 5) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 5>(p, lc, stream);
         return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 4>(p, lc, stream);
     case kNodesWide:
+        if (lc.waves_per_simd == 8) return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 8>(p, lc, stream);
         if (lc.waves_per_simd == 7) return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 7>(p, lc, stream);
         if (lc.waves_per_simd == 6) return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 6>(p, lc, stream);
         if (lc.waves_per_simd == 5) return launch_one<SPLIT, kNodesWide, 256, COUNT, SCHED, 5>(p, lc, stream);

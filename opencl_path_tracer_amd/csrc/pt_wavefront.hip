@@ -151,13 +151,16 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
     const float4* __restrict__ rsB = w.rsB[bounce & 1][cost];
     float2* __restrict__ hits = w.hit[cost];
     const unsigned long long lt = lanemask_lt();
-    const unsigned wave = threadIdx.x >> 6;
+    // wave-uniform loop state (wave index, the cursor cbase / cend of the wave's ray range) is kept in scalar registers
+    // -- readfirstlane at every redefinition -- so that it can never be spilled lane by lane under a partial exec mask
+    // (the hang class of profiles/r02/v_*; tools/check_isa.py checks every instance)
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WorkCount wc;
     // the grid only fills the chip: a block takes the trips block_base = blockIdx.x * RPB, + gridDim.x * RPB, ...
     // (the nodes are staged once per block, not once per 1,024 rays)
     for (unsigned block_base = blockIdx.x * RPB; block_base < n; block_base += gridDim.x * RPB) {
-        unsigned cbase = block_base + wave * kWfRaysPerWave;  // uniform per wave: next unassigned ray
-        const unsigned cend = min(cbase + (unsigned)kWfRaysPerWave, n);
+        unsigned cbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(block_base + wave * kWfRaysPerWave));  // uniform per wave: next unassigned ray
+        const unsigned cend = (unsigned)__builtin_amdgcn_readfirstlane((int)min(cbase + (unsigned)kWfRaysPerWave, n));
         if (cbase > cend) cbase = cend;
         Trav<MODE> tr;
         // the big-triangle list first, for the wave's whole range with every lane busy: the hit record of a ray
@@ -200,7 +203,7 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
                     nB = *reinterpret_cast<const float2*>(&rsB[my]);
                     if (sv.n_flat > 0) nH = hits[my];
                 }
-                cbase = min(cbase + (unsigned)__popcll(want), cend);
+                cbase = (unsigned)__builtin_amdgcn_readfirstlane((int)min(cbase + (unsigned)__popcll(want), cend));
             }
             if (__ballot(!tr.done() || npos != ~0u) == 0) break;
             // ---- while-while rounds until at most kWfSuspendLanes lanes are unfinished (and one has finished): the
@@ -290,8 +293,12 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
             const float4 C = w.sC[li], Dq = w.sD[li], E = w.sE[li];
             rP = mk(A.x, A.y, A.z);
             rD = mk(A.w, B.x, B.y);
-            f3 fL = mk(C.x, C.y, C.z), fB = mk(C.w, Dq.x, Dq.y), fS = mk(Dq.z, Dq.w, E.x), fR = mk(E.y, E.z, E.w);
-            shade_hit(rP, rD, fL, fB, fS, fR, color, seed, inside, p, p.tris, p.meta, __float_as_int(h.y), h.x);
+            PathRegs st;
+            st.fL = mk(C.x, C.y, C.z); st.fB = mk(C.w, Dq.x, Dq.y); st.fS = mk(Dq.z, Dq.w, E.x); st.fR = mk(E.y, E.z, E.w);
+            st.color = color;
+            shade_hit<false>(rP, rD, st, seed, inside, p, p.tris, p.meta, __float_as_int(h.y), h.x);
+            const f3 fL = st.fL, fB = st.fB, fS = st.fS, fR = st.fR;
+            color = st.color;
             if (bounce + 1 >= p.iterations) {
                 wf_finalize(w, li, color, seed);
             } else {
@@ -321,10 +328,9 @@ static hipError_t launch_wf_intersect_t(const WfParams& w, int bounce, int resid
     constexpr int RPB = (BLOCK / 64) * kWfRaysPerWave;
     const size_t lds = traversal_lds_bytes(w.rp, BLOCK) + RPB + (RPB / 64) * 3 * 4 + 32;
     auto kern = wf_intersect<MODE, BLOCK>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    static LdsMark mark;
+    const hipError_t e = ensure_dynamic_lds((const void*)kern, mark, lds);
+    if (e != hipSuccess) return e;
     const int blocks = std::min((w.npix + RPB - 1) / RPB, resident_blocks);
     if (w.rp.stack_ovf && 2ll * blocks * BLOCK > (long long)w.rp.stack_ovf_lanes) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(blocks, 2), dim3(BLOCK), lds, stream, w, bounce);

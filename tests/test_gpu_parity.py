@@ -800,6 +800,11 @@ def test_gather_frame_through_rccl_one_rank(api, oracle, cb_spec, cb_oracle_scen
     assert sc.device_frame() != sc.device_colors()
     fr, _ = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 4, 2)
     assert same_bits(sc.read_frame()[:, :3], fr.colors()[:, :3])
+    sc.render(1)                                                 # the gathered frame is now older than colors: never served
+    assert sc.device_frame() == sc.device_colors()
+    assert same_bits(sc.read_frame(), sc.read_colors())
+    sc.gather_frame()
+    assert sc.device_frame() != sc.device_colors() and same_bits(sc.read_frame(), sc.read_colors())
     with pytest.raises(api.PtError):
         sc.comm_init(api.comm_unique_id())                       # a context has one communicator
     t = api.Scene(W, H, rank=1, world=2, rows_per_block=8).load(cb_spec)
@@ -868,18 +873,33 @@ def test_schedules_identical(api, oracle, cb_spec, cb_oracle_scene, schedule, k)
         assert sc.stat("segments") == segs2
 
 
-def _mesh100k_from_obj(api, oracle, tmp_path, W, H, pre=None, **ctx_kw):
-    """BASELINE config 3 as SURVEY 8(d) words it: the Cornell walls authored with add_Triangle
-    (main.cpp:793-815) + MESH-100k written as OBJ+MTL (Kd/Ks/Ke/Ns/Kn/Kk/Tp, shared vertices, three usemtl
+_OBJ_CACHE = {}
+
+
+def _mesh_obj_file(oracle, ntris):
+    """The OBJ+MTL of a displaced-grid mesh, written once per test session, + what the loader must make of it."""
+    if ntris not in _OBJ_CACHE:
+        import atexit
+        import shutil
+        import tempfile
+        from opencl_path_tracer_amd import scenes
+        d = tempfile.mkdtemp(prefix="ptamd_obj_%d_" % ntris)
+        atexit.register(shutil.rmtree, d, ignore_errors=True)
+        pos, scale, pitch, yaw = (40.0, -15.0, 25.0), (2.0, 2.0, 2.0), 10.0, 30.0
+        path, local, faces, band = scenes.write_grid_mesh_obj(ntris, d, pos, scale, pitch, yaw)
+        world = np.array([oracle.obj_vertex(v, pos, scale, pitch, yaw) for v in local], dtype=np.float32)
+        _OBJ_CACHE[ntris] = (path, (pos, scale, pitch, yaw), world[faces], (len(scenes.BUILTIN_MATERIALS) + band).astype(np.uint16))   # mat_offset, main.cpp:562
+    return _OBJ_CACHE[ntris]
+
+
+def _mesh100k_from_obj(api, oracle, tmp_path, W, H, pre=None, ntris=100000, **ctx_kw):
+    """BASELINE configs 3 / 5 as SURVEY 8(d) words them: the Cornell walls authored with add_Triangle
+    (main.cpp:793-815) + MESH-100k / MESH-1M written as OBJ+MTL (Kd/Ks/Ke/Ns/Kn/Kk/Tp, shared vertices, three usemtl
     bands) and loaded with pt_add_obj under a non-trivial pos/scale/pitch/yaw.  Returns the product scene,
     and the vertices / material indices the loader must have authored (the oracle's restatement of
     main.cpp:598-606 applied to the numbers in the file)."""
     from opencl_path_tracer_amd import scenes
-    pos, scale, pitch, yaw = (40.0, -15.0, 25.0), (2.0, 2.0, 2.0), 10.0, 30.0
-    path, local, faces, band = scenes.write_grid_mesh_obj(100000, str(tmp_path), pos, scale, pitch, yaw)
-    world = np.array([oracle.obj_vertex(v, pos, scale, pitch, yaw) for v in local], dtype=np.float32)
-    verts = world[faces]
-    mati = (len(scenes.BUILTIN_MATERIALS) + band).astype(np.uint16)        # mat_offset, main.cpp:562
+    path, (pos, scale, pitch, yaw), verts, mati = _mesh_obj_file(oracle, ntris)
     sc = api.Scene(W, H, **ctx_kw)
     for k, v in (pre or {}).items():           # options the upload depends on
         sc.set_option(k, v)
@@ -896,11 +916,11 @@ def _mesh100k_from_obj(api, oracle, tmp_path, W, H, pre=None, **ctx_kw):
 
 
 @pytest.mark.timeout(300, method="thread")
-@pytest.mark.parametrize("waves", [4, 5, 6, 7])
+@pytest.mark.parametrize("waves", [4, 5, 6, 7, 8])
 def test_register_budgets_of_the_global_memory_kernels(api, oracle, cb_spec, cb_oracle_scene, waves):
     """Every k_render instance that reads nodes from global memory -- BVH2 and 4-wide nodes, both schedules, with and
-    without chained passes -- at each register budget (4 / 5 / 6 / 7 waves per SIMD = 128 / 96 / 80 / 72 VGPRs): same
-    frame.  (The instances differ in nothing but what the compiler spills -- which is how a wave-uniform work item kept
+    without chained passes -- at each register budget (4 / 5 / 6 / 7 / 8 waves per SIMD = 128 / 96 / 80 / 72 / 64 VGPRs;
+    the eighth needs stacks short enough for eight workgroups per CU): same frame.  (The instances differ in nothing but what the compiler spills -- which is how a wave-uniform work item kept
     in a VGPR came back wrong from a spill made under a partial exec mask: profiles/r02/v_seven_waves_*.)"""
     from opencl_path_tracer_amd import scenes
     W, H = 80, 56
@@ -920,6 +940,8 @@ def test_register_budgets_of_the_global_memory_kernels(api, oracle, cb_spec, cb_
             for wide in (0, 1):
                 sc = api.Scene(64, 64)
                 sc.set_option("wide_nodes", wide)
+                if waves == 8:
+                    sc.set_option("wide_lds_entries", 16)
                 sc.load(spec)
                 for k, v in (("waves_per_simd", waves), ("schedule", schedule), ("chunk_spp", chunk)):
                     sc.set_option(k, v)
@@ -989,6 +1011,70 @@ def test_full_size_properties_mesh_1080p(api, oracle, tmp_path):
         t, _, _ = _mesh100k_from_obj(api, oracle, tmp_path, W, H, rank=r, world=2, rows_per_block=8)
         t.iterations = B
         t.render(3)
+        ids = t.local_pixel_ids()
+        full_c[ids] = t.read_colors()
+        full_r[ids] = t.read_rnds()
+        del t
+    assert same_bits(ca, full_c) and np.array_equal(ra, full_r)
+
+
+@pytest.mark.timeout(900, method="thread")
+def test_config5_mesh1m_through_add_obj(api, oracle):
+    """BASELINE config 5 as it is worded -- "1M-triangle OBJ scene, 16 bounces": MESH-1M written as a 52-MB OBJ+MTL and
+    loaded with pt_add_obj (main.cpp:552-617) under a non-trivial transform: the triangles the loader authored == the
+    array path fed with the oracle's restatement of main.cpp:598-606 on the file's numbers, bit for bit (1,002,528 of
+    them); then 48x48 x 16 bounces == the oracle on those triangles."""
+    from opencl_path_tracer_amd import scenes
+    W, H, B = 48, 48, 16
+    sc, verts, mati = _mesh100k_from_obj(api, oracle, None, W, H, ntris=1000000)
+    tris, mats, objs = sc.debug_scene()
+    assert sc.stat("flat_triangles") == 12 and objs.tolist() == [0, 12] and tris.shape[0] == 12 + verts.shape[0] > 1000000
+    assert tris[12:].tobytes() == api.triangles_from_vertices(verts, mati).tobytes()
+    assert sc.stat("node_mode") == 3
+    osc = oracle.OracleScene()
+    for m in list(scenes.BUILTIN_MATERIALS) + [scenes.BUILTIN_MATERIALS[i] for i in (scenes.WHITE_DIFFUSE, scenes.CHROMIUM, scenes.GLASS)]:
+        osc.add_Material(*m)
+    wv, wm = scenes.cornell_walls()
+    osc.add_triangles(wv, wm)
+    osc.end_Obj()
+    osc.add_triangles(verts, mati)
+    osc.end_Obj()
+    sc.iterations = B
+    sc.render(2)
+    cam = oracle.make_camera(60.0, 0.0, 0.0, (0.0, 0.0, 0.0), W, H)
+    fr = oracle.OracleFrame(W, H)
+    segs = fr.render(osc, cam, B, 0, 2, mode=0, nthreads=16)
+    check(sc, fr, "config 5 through pt_add_obj")
+    assert sc.stat("segments") == segs
+
+
+@pytest.mark.timeout(900, method="thread")
+def test_full_size_properties_mesh1m_1080p(api, oracle):
+    """BASELINE config 5 at full size (OBJ-loaded MESH-1M, 1920x1080, 16 bounces): k samples in one launch == k launches
+    of one == the lockstep schedule == another kernel instance (BVH2 nodes at 5 waves per SIMD with chained passes of one
+    sample); the union of two ranks' tiles == the single-context frame."""
+    W, H, B = 1920, 1080, 16
+    a, _, _ = _mesh100k_from_obj(api, oracle, None, W, H, ntris=1000000)
+    a.iterations = B
+    a.render(2)
+    ca, ra = a.read_colors(), a.read_rnds()
+    assert float(ca[:, :3].sum()) > 0 and a.stat("node_mode") == 3
+    del a
+    for opts in ({"steps": 2}, {"schedule": 0}, {"pre": {"wide_nodes": 0}, "waves_per_simd": 5, "chunk_spp": 1}):
+        b, _, _ = _mesh100k_from_obj(api, oracle, None, W, H, pre=opts.pop("pre", None), ntris=1000000)
+        steps = opts.pop("steps", 1)
+        for k, v in opts.items():
+            b.set_option(k, v)
+        b.iterations = B
+        for _ in range(steps):
+            b.render(2 // steps)
+        assert same_bits(ca, b.read_colors()) and np.array_equal(ra, b.read_rnds()), str(opts)
+        del b
+    full_c, full_r = np.zeros_like(ca), np.zeros_like(ra)
+    for r in range(2):
+        t, _, _ = _mesh100k_from_obj(api, oracle, None, W, H, ntris=1000000, rank=r, world=2, rows_per_block=8)
+        t.iterations = B
+        t.render(2)
         ids = t.local_pixel_ids()
         full_c[ids] = t.read_colors()
         full_r[ids] = t.read_rnds()

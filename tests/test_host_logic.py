@@ -26,11 +26,16 @@ def test_encounter_rank_matches_oracle(api, oracle, cb_spec, cb_oracle_scene):
 
 
 def test_encounter_rank_on_mesh(api, oracle):
+    """The flattened, threaded restatement of NodeOnHost::build's leaf order (main.cpp:210-262) == the oracle's
+    recursive one, for the serial path (small object) and with the top of the tree cut into parallel tasks."""
     from opencl_path_tracer_amd import scenes
-    spec = scenes.displaced_grid_mesh(6000)
-    sc = api.Scene(16, 16, device=None).load(spec)
-    osc = oracle.load_scene(spec)
-    assert np.array_equal(sc.debug_encounter_rank(spec.ntris), osc.encounter_rank())
+    for ntris, threads in ((6000, 0), (60000, 1), (60000, 3), (60000, 0)):
+        spec = scenes.displaced_grid_mesh(ntris)
+        sc = api.Scene(16, 16, device=None)
+        sc.set_option("build_threads", threads)
+        sc.load(spec)
+        osc = oracle.load_scene(spec)
+        assert np.array_equal(sc.debug_encounter_rank(spec.ntris), osc.encounter_rank()), (ntris, threads)
 
 
 def test_bvh_structure(api, cb_spec):

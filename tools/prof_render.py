@@ -11,7 +11,7 @@ scene = opts.pop("scene", "cornell")
 spec = {"cornell": scenes.cornell_box, "mesh100k": lambda: scenes.displaced_grid_mesh(100000),
         "mesh1m": lambda: scenes.displaced_grid_mesh(1000000)}[scene]()
 sc = api.Scene(W, H)
-pre = ("bvh_policy", "treelet", "lds_scene", "flat_list")          # options the upload depends on
+pre = ("bvh_policy", "treelet", "lds_scene", "flat_list", "wide_nodes", "wide_lds_entries", "sah_visit_cost")          # options the upload depends on
 for k in pre:
     if k in opts:
         sc.set_option(k, int(opts[k]))
