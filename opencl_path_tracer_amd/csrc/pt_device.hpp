@@ -422,17 +422,17 @@ struct Trav {
         int li, ri;
         if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; }
         if (KIND == kVisitLds) {
-            const char* nb = reinterpret_cast<const char*>(sv.lds_nodes) + ((size_t)(unsigned)cur << 6);
+            const char* nb = reinterpret_cast<const char*>(sv.lds_nodes) + (unsigned)cur * (unsigned)kLdsNodeBytes;
             const float2 ex = *reinterpret_cast<const float2*>(nb + onx), xx = *reinterpret_cast<const float2*>(nb + (onx ^ 8));
             const float2 ey = *reinterpret_cast<const float2*>(nb + ony), xy = *reinterpret_cast<const float2*>(nb + (ony ^ 8));
             const float2 ez = *reinterpret_cast<const float2*>(nb + onz), xz = *reinterpret_cast<const float2*>(nb + (onz ^ 8));
-            const int2 ch = *reinterpret_cast<const int2*>(nb + 48);
+            const unsigned chw = *reinterpret_cast<const unsigned*>(nb + 48);       // left | right << 16
             ln = fmaxf(fmaxf(fmaf_(ex.x, inv.x, cn.x), fmaf_(ey.x, inv.y, cn.y)), fmaf_(ez.x, inv.z, cn.z));
             rn = fmaxf(fmaxf(fmaf_(ex.y, inv.x, cn.x), fmaf_(ey.y, inv.y, cn.y)), fmaf_(ez.y, inv.z, cn.z));
             lf = fminf(fminf(fmaf_(xx.x, inv.x, cf.x), fmaf_(xy.x, inv.y, cf.y)), fmaf_(xz.x, inv.z, cf.z)) * kWiden;
             rf = fminf(fminf(fmaf_(xx.y, inv.x, cf.x), fmaf_(xy.y, inv.y, cf.y)), fmaf_(xz.y, inv.z, cf.z)) * kWiden;
-            li = ch.x;
-            ri = ch.y;
+            li = (int)(chw & 0xffffu);
+            ri = (int)(chw >> 16);
         } else {
             // (unsigned 32-bit byte offsets: scalar base + vector offset addressing, no 64-bit address
             // math; pt_add_triangles caps the scene so that they cannot wrap)
@@ -856,18 +856,30 @@ PT_DEV f3 running_mean(f3 acc, f3 color, int s) {   // prog.cl:379
 // (or exit) planes of BOTH children for a ray whose direction sign on that axis is known
 // (Trav::node_step, kVisitLds), and the child slots of the fourth quad are re-encoded to the 16-bit
 // reference form.  The treelet of a large tree is staged verbatim (kVisitFlat reads both copies alike).
-PT_DEV float stage_ref(float slot) {
+PT_DEV unsigned stage_ref(float slot) {
     const int r = __float_as_int(slot);
-    return __int_as_float(r < 0 ? (0x8000 | ~r) : r);
+    return (unsigned)(r < 0 ? (0x8000 | ~r) : r) & 0xffffu;
 }
 template <int MODE>
 PT_DEV void stage_nodes(const RenderParams& p, float4* lds_nodes) {
-    const int nn = (MODE == kNodesLds ? p.n_nodes : p.treelet_nodes) * 4;
+    if (MODE != kNodesLds) {                     // the treelet of a large tree: verbatim
+        const int nn = p.treelet_nodes * 4;
+        for (int i = threadIdx.x; i < nn; i += blockDim.x) lds_nodes[i] = p.nodes[i];
+        return;
+    }
+    // whole tree: kLdsNodeBytes per node -- {L.lo, R.lo, L.hi, R.hi} per axis, then left | right << 16
+    char* out = reinterpret_cast<char*>(lds_nodes);
+    const int nn = p.n_nodes * 4;
     for (int i = threadIdx.x; i < nn; i += blockDim.x) {
         const float4 q = p.nodes[i];
-        if (MODE != kNodesLds) lds_nodes[i] = q;
-        else if ((i & 3) != 3) lds_nodes[i] = make_float4(q.x, q.z, q.y, q.w);
-        else lds_nodes[i] = make_float4(stage_ref(q.x), stage_ref(q.y), q.z, q.w);
+        char* nb = out + (unsigned)(i >> 2) * (unsigned)kLdsNodeBytes;
+        if ((i & 3) != 3) {
+            float2* d = reinterpret_cast<float2*>(nb + (i & 3) * 16);
+            d[0] = make_float2(q.x, q.z);
+            d[1] = make_float2(q.y, q.w);
+        } else {
+            *reinterpret_cast<unsigned*>(nb + 48) = stage_ref(q.x) | (stage_ref(q.y) << 16);
+        }
     }
 }
 
@@ -878,7 +890,7 @@ PT_DEV size_t traversal_stack_bytes_dev(const RenderParams& p) {
 }
 template <int MODE, int BLOCK>
 PT_DEV size_t traversal_nodes_end_dev(const RenderParams& p) {
-    return traversal_stack_bytes_dev<MODE, BLOCK>(p) + (MODE == kNodesLds ? (size_t)p.n_nodes * 64 : MODE == kNodesTreelet ? (size_t)p.treelet_nodes * 64 : 0);
+    return traversal_stack_bytes_dev<MODE, BLOCK>(p) + (MODE == kNodesLds ? (((size_t)p.n_nodes * kLdsNodeBytes + 15) & ~(size_t)15) : MODE == kNodesTreelet ? (size_t)p.treelet_nodes * 64 : 0);
 }
 template <int MODE, int BLOCK>
 PT_DEV size_t traversal_lds_bytes_dev(const RenderParams& p) {      // == traversal_lds_bytes() on the host

@@ -90,7 +90,7 @@ struct pt_context {
     float4* d_ldr = nullptr;
     unsigned long long* d_stats = nullptr;
     // wavefront variant: path state + queues (allocated on first use)
-    float4* d_wf_state = nullptr;   // 4 (state) + 8 (ray streams) x npix float4, + 2 x npix float2 (hits)
+    float4* d_wf_state = nullptr;   // per local pixel: 4 float4 worth of path factors + colour (5 x 12 B), 8 float4 of ray streams, 2 float2 of hits
     int32_t* d_wf_queues = nullptr; // 3 x npix int32 (class queues)
     std::vector<float> cost_boxes;  // 6 floats per complex object (wavefront cost classes)
     uint32_t* d_wf_counters = nullptr;
@@ -124,6 +124,7 @@ struct pt_context {
     int build_threads = 0; // host SAH builder: threads (0: the machine's, at most 16); the tree is the same for any number
     int wide_nodes = 1;    // 4-wide quantised nodes: 0 never, 1 for trees that do not fit LDS, 2 for every tree (tests)
     int wide_lds_entries = kWideLdsEntries;   // 4-wide traversal: stack entries per lane kept in LDS (tests lower it to force the global part)
+    int lds_block = -1;      // whole tree in LDS: threads per workgroup of k_render: -1 768 where two such workgroups fit a CU, 512 (tests)
     int waves_per_simd = -1; // nodes from global memory: register budget for 4 / 5 / 6 / 7 waves per SIMD (-1: the most the LDS stacks allow)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
@@ -764,8 +765,8 @@ constexpr size_t kLdsSlack = 32 * 100 + 4096 + 1024 + 256;
 // Does the whole tree fit next to two 512-thread workgroups per CU (kNodesLds: 16-bit references)?
 bool whole_tree_fits_lds(size_t n_nodes, size_t n_tris, int interior_depth, int n_flat) {
     const bool s16 = n_nodes <= 32767 && n_tris <= 4096;
-    const size_t block = (size_t)std::max(kLdsRenderBlock, 512);     // (k_render; wf_intersect and the debug kernel use 512)
-    return s16 && sizeof(Node64) * n_nodes + (size_t)stack_entries_for(interior_depth) * 2 * block + (size_t)n_flat * 100 + 64 <= kLdsPerCu / 2;   // (+ flat list: packet + box + group mask per triangle)
+    const size_t block = (size_t)kLdsBlockBase;      // (the 768-thread k_render instance is taken only where it fits too)
+    return s16 && (size_t)kLdsNodeBytes * n_nodes + 16 + (size_t)stack_entries_for(interior_depth) * 2 * block + (size_t)n_flat * 100 + 64 <= kLdsPerCu / 2;   // (+ flat list: packet + box + group mask per triangle)
 }
 
 // Treelet: when the tree is too large for LDS, the T nodes with the largest boxes --
@@ -1477,7 +1478,13 @@ int pt_upload_seeds(pt_context* ctx, const int32_t* seeds, int64_t n) {
 static int ptamd_resident_waves(const pt_context*, const LaunchConfig& lc) { return lc.persistent_blocks * (lc.block / 64); }
 
 static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc) {
-    lc->block = traversal_block(p.node_mode);
+    // whole tree in LDS: two 768-thread workgroups per CU (six waves per SIMD) if their LDS fits, else two of 512
+    // -- and if the launch has a tile for each of their waves: with fewer (a 1080p frame over 8 GPUs: 4,050 tiles for
+    // 6,144 waves) the extra waves stay empty and the 128-VGPR instance runs each tile faster (profiles/r03/g_*)
+    const bool wide_fits = p.node_mode == kNodesLds && 2 * (traversal_lds_bytes(p, kLdsBlockWide) + 512) <= kLdsPerCu;
+    const bool wide_block = wide_fits && ctx->lds_block != kLdsBlockBase &&
+                            (ctx->lds_block == kLdsBlockWide || p.n_tiles >= ctx->cu_count * 2 * (kLdsBlockWide / 64));
+    lc->block = traversal_block(p.node_mode, wide_block);
     lc->lds_bytes = traversal_lds_bytes(p, lc->block);
     lc->count_work = ctx->count_work != 0;
     // Restart + tail suspension wins when a wave works through many tiles (one GPU, 1080p: 7.9 per resident wave:
@@ -1487,7 +1494,7 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
     // 95.7 % against 88 %; profiles/r02/e_*, q_*).
     // resident workgroups at 4 waves per SIMD: 2 x 512 threads (whole tree in LDS), 1 x 1024 (treelet) per CU; nodes through
     // L1/L2 (256 threads): as many waves per SIMD -- 7, 6, 5 or 4 -- as the stacks in LDS leave room for
-    lc->waves_per_simd = p.node_mode == kNodesLds ? kLdsRenderWps : 4;
+    lc->waves_per_simd = wide_block ? kLdsWpsWide : 4;
     if (p.node_mode == kNodesGlobal || p.node_mode == kNodesWide) {
         const int want = ctx->waves_per_simd > 0 ? ctx->waves_per_simd : 7;
         for (int w = std::min(want, 8); w > 4; --w)
@@ -1543,8 +1550,7 @@ static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsa
     }
     WfParams w;
     w.rp = rp;
-    w.sC = ctx->d_wf_state + 0 * np; w.sD = ctx->d_wf_state + 1 * np;
-    w.sE = ctx->d_wf_state + 2 * np; w.sF = ctx->d_wf_state + 3 * np;
+    w.sP = reinterpret_cast<float*>(ctx->d_wf_state);        // kWfFields x np x 12 B <= 4 x np x 16 B
     for (int par = 0; par < 2; ++par)
         for (int c = 0; c < 2; ++c) {
             w.rsA[par][c] = ctx->d_wf_state + (size_t)(4 + (par * 2 + c) * 2 + 0) * np;
@@ -1613,7 +1619,7 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         // passes of 8, lockstep with whole tiles (profiles/r02/q_*: 95.7 % / 87.5 % / 61.8 % of the one-GPU rate per GPU)
         const int auto_chunk = p.n_tiles >= 5 * resident_waves ? (nsamples >= 256 ? 64 : 32)
                              : p.n_tiles >= 3 * resident_waves ? 16
-                             : p.n_tiles > resident_waves + resident_waves / 2 ? 8 : 0;
+                             : p.n_tiles > resident_waves + resident_waves / 4 ? 8 : 0;
         const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk;
         // work items are numbered with an int on the device: passes x tiles + one failed fetch per resident wave
         const int64_t items = chunk > 0 ? ((int64_t)nsamples + chunk - 1) / chunk * p.n_tiles : p.n_tiles;
@@ -1865,6 +1871,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "waves_per_simd") {
         if (value != -1 && (value < 4 || value > 8)) return fail(ctx, PT_EINVAL, "waves_per_simd: -1 automatic (at most 7), 4..8 (kernels that read nodes from global memory)");
         ctx->waves_per_simd = (int)value;
+    } else if (k == "lds_block") {
+        if (value != -1 && value != kLdsBlockBase && value != kLdsBlockWide) return fail(ctx, PT_EINVAL, "lds_block: -1 automatic, 512 or 768");
+        ctx->lds_block = (int)value;
     } else if (k == "debug_repeat") {
         if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "debug_repeat: 0..1000 extra timed launches");
         ctx->debug_repeat = (int)value;
@@ -1986,7 +1995,7 @@ int pt_debug_closest_hit(pt_context* ctx, const pt_ray* rays, int64_t n, float* 
     PT_HIP(ctx, d_t.alloc(sizeof(float) * (size_t)n));
     PT_HIP(ctx, d_tri.alloc(sizeof(int32_t) * (size_t)n));
     if (n) PT_HIP(ctx, hipMemcpy(d_rays.p, rays, sizeof(pt_ray) * (size_t)n, hipMemcpyHostToDevice));
-    ctx->last_lds_bytes = traversal_lds_bytes(p, traversal_block(p.node_mode));
+    ctx->last_lds_bytes = traversal_lds_bytes(p, traversal_block(p.node_mode, false));
     PT_HIP(ctx, launch_debug_closest_hit(p, (const pt_ray*)d_rays.p, n, (float*)d_t.p, (int32_t*)d_tri.p, ctx->cu_count, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->debug_repeat > 0) {      // traversal-only timing: the same launch, debug_repeat times

@@ -74,14 +74,20 @@ constexpr int kStatCols = 16;
 #define PT_LEAN_FROM_WPS 6
 #endif
 constexpr int kLeanFromWps = PT_LEAN_FROM_WPS;
-// the k_render instance for a tree staged whole in LDS: threads per workgroup / waves per SIMD (two workgroups per CU either
-// way).  A/B switch: 640 / 5 = a fifth wave per SIMD at 96 VGPRs
-#ifndef PT_LDS_BLOCK
-#define PT_LDS_BLOCK 512
-#define PT_LDS_WPS 4
+// The k_render instances for a tree staged whole in LDS (two workgroups per CU either way): 2 x 768 threads at an 80-VGPR
+// budget = six waves per SIMD when the LDS has room for it (12 waves per workgroup = 3 per SIMD: any placement of the two
+// workgroups fits; 2 x 640 at 96 VGPRs does not -- 10 waves land 3+3+2+2 and the second workgroup finds two SIMDs full,
+// which is what made "five waves" lose 30 % in round 2), otherwise 2 x 512 at 128 VGPRs.  Cornell box: 2,050 -> 2,349
+// Msamples/s (profiles/r03/f_*).
+constexpr int kLdsBlockWide = 768, kLdsWpsWide = 6;
+constexpr int kLdsBlockBase = 512, kLdsWpsBase = 4;
+// a node of a tree staged whole in LDS (kNodesLds): three swizzled box quads + both 16-bit child references in one word,
+// 52 B padded to 56.  Not 64: a 14-dword stride puts the same field of 32 different nodes on 32 different bank pairs
+// (a 16-dword stride on 4), and 7.5 KB less per workgroup is what lets two 768-thread workgroups share a CU
+#ifndef PT_LDS_NODE_BYTES
+#define PT_LDS_NODE_BYTES 56
 #endif
-constexpr int kLdsRenderBlock = PT_LDS_BLOCK;
-constexpr int kLdsRenderWps = PT_LDS_WPS;
+constexpr int kLdsNodeBytes = PT_LDS_NODE_BYTES;
 constexpr int kStackEntries = 36;  // upper bound of the per-lane traversal stack: sentinel + far children + one slot above the top
 
 // ---- kernel parameter block (passed by value, like `Camera` in prog.cl:292-304) ----------
@@ -120,23 +126,27 @@ struct RenderParams {
 };
 
 // ---- wavefront (stream-compacted) formulation
-// Per local pixel (index li), 64 B:  sC = {fL.xyz, fB.x}  sD = {fB.yz, fS.xy}  sE = {fS.z, fR.xyz}
-//                                    sF = {color.xyz, bits(seed | inside << 31)}
+// Per local pixel (index li): the four path factors and the colour, five arrays of 12-B records sP[field][li]
+// (kWfL .. kWfC).  A field is read only if it was written in this sample and written only by the material that changes it
+// (PathInHbm, pt_wavefront.hip); the LCG state stays in rnds[li].
 // Ray streams, one per (bounce parity, cost class), addressed by POSITION (compact, written and
-// read coalesced), 32 B per ray:     rsA = {P.xyz, D.x}  rsB = {D.y, D.z, bits(li), 0}
+// read coalesced), 32 B per ray:     rsA = {P.xyz, D.x}  rsB = {D.y, D.z, bits(li), bits(flags)}
+//                                    flags: bit f (f < 5) = field f of sP is valid; bit 5 = the path is inside glass
 // Hit stream, parallel to the ray stream of the current bounce, 8 B:  hit = {t, bits(tri)}
 // Class queues (shade input): entries (cost << 31) | position.
 // Counter rows (kWfCounterStride words each), see wf_row(): 0 n_ray cheap, 1 n_ray expensive,
-// 2..4 n_class A/B/C.  Row 0 belongs to bounce 0 (filled by wf_generate, cleared by a memset in
+// 2..4 n_class A/B/C, 5 / 6 next unassigned ray of the cheap / expensive stream (wf_intersect's work fetch).
+// Row 0 belongs to bounce 0 (filled by wf_generate, cleared by a memset in
 // front of it); bounce b >= 1 uses row b + 1 (cleared by wf_generate).
 constexpr int kWfCounterStride = 8;
 constexpr int kWfMaxBounces = 1023;
 constexpr int kWfGenRow = 0;
 __host__ __device__ inline int wf_row(int bounce) { return bounce == 0 ? kWfGenRow : bounce + 1; }
 constexpr int kWfMaxCostBoxes = 8;
+enum : int { kWfL = 0, kWfB = 1, kWfS = 2, kWfR = 3, kWfC = 4, kWfFields = 5, kWfInsideBit = 1 << 5 };
 struct WfParams {
     RenderParams rp;
-    float4 *sC, *sD, *sE, *sF;
+    float* sP;             // [kWfFields][npix] x 3 floats
     float4* rsA[2][2];     // [bounce parity][cost class]
     float4* rsB[2][2];
     float2* hit[2];        // [cost class]
@@ -190,7 +200,7 @@ inline hipError_t ensure_dynamic_lds(const void* kern, LdsMark& mark, size_t lds
 }
 
 // launchers (pt_kernels.hip, pt_wavefront.hip, pt_debug.hip); all asynchronous on `stream`
-int traversal_block(int node_mode);                            // threads per workgroup of the traversal kernels
+int traversal_block(int node_mode, bool wide_lds_block);       // threads per workgroup of k_render
 size_t traversal_lds_bytes(const RenderParams& p, int block);  // stacks + staged nodes
 hipError_t launch_gen_ray(const RenderParams& p, hipStream_t stream);
 hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream);

@@ -404,12 +404,12 @@ static inline int n_waves(const RenderParams& p) {
     return tiles_x * tiles_y;
 }
 
-int traversal_block(int node_mode) { return node_mode == kNodesLds ? kLdsRenderBlock : node_mode == kNodesTreelet ? 1024 : 256; }      // of k_render
+int traversal_block(int node_mode, bool wide_lds_block) { return node_mode == kNodesLds ? (wide_lds_block ? kLdsBlockWide : kLdsBlockBase) : node_mode == kNodesTreelet ? 1024 : 256; }
 
 size_t traversal_lds_bytes(const RenderParams& p, int block) {
     size_t b = (size_t)p.stack_entries * (p.node_mode == kNodesLds ? 2 : 4) * (size_t)block;
     b = (b + 15) & ~(size_t)15;
-    if (p.node_mode == kNodesLds) b += (size_t)p.n_nodes * 64;
+    if (p.node_mode == kNodesLds) b += ((size_t)p.n_nodes * kLdsNodeBytes + 15) & ~(size_t)15;
     if (p.node_mode == kNodesTreelet) b += (size_t)p.treelet_nodes * 64;
     return b + (size_t)p.n_flat * 100;         // the big-triangle list's packets, padded boxes and box-group masks
 }
@@ -440,9 +440,11 @@ static hipError_t launch_one(const RenderParams& p, const LaunchConfig& lc, hipS
 
 template <bool SPLIT, bool COUNT, int SCHED>
 static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
-    if (lc.block != traversal_block(p.node_mode)) return hipErrorInvalidValue;
+    if (lc.block != traversal_block(p.node_mode, lc.block == kLdsBlockWide)) return hipErrorInvalidValue;
     switch (p.node_mode) {
-    case kNodesLds: return launch_one<SPLIT, kNodesLds, kLdsRenderBlock, COUNT, SCHED, kLdsRenderWps>(p, lc, stream);
+    case kNodesLds:
+        if (lc.block == kLdsBlockWide) return launch_one<SPLIT, kNodesLds, kLdsBlockWide, COUNT, SCHED, kLdsWpsWide>(p, lc, stream);
+        return launch_one<SPLIT, kNodesLds, kLdsBlockBase, COUNT, SCHED, kLdsWpsBase>(p, lc, stream);
     case kNodesGlobal:
         if (lc.waves_per_simd == 8) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 8>(p, lc, stream);
         if (lc.waves_per_simd == 7) return launch_one<SPLIT, kNodesGlobal, 256, COUNT, SCHED, 7>(p, lc, stream);

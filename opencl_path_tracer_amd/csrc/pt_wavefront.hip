@@ -17,9 +17,10 @@ namespace ptamd {
 //                 range) while the stragglers carry on.  At the end of its range the block
 //                 compacts its rays into three class queues by the material type they hit
 //                 (order-preserving ballot scan through LDS, 3 global atomics per 1,024 rays).
-//   wf_shade    : one block row per class -> waves are material-coherent.  Survivors go to the
-//                 next bounce's ray queues; paths that end (miss / last bounce) fold their colour
-//                 into the running mean (prog.cl:379) and store the LCG state.
+//   wf_shade    : one block row per class -> waves are material-coherent.  A hit moves only the part of the path state
+//                 its material touches (PathInHbm): diffuse fL + fB, mirror fS, dielectric fR, an emitter reads what
+//                 was ever written and adds to the colour.  Survivors go to the next bounce's ray queues; paths that
+//                 end (miss / last bounce) fold their colour into the running mean (prog.cl:379).
 // Ray queues come in two COST classes: a ray that misses the bounding boxes of every complex
 // object (more than 16 triangles) can only hit the few large triangles around them and finishes
 // in a handful of steps; mixing it into a wave with rays that walk a 1,000-triangle object leaves
@@ -76,7 +77,7 @@ PT_DEV int ray_cost_class(const WfParams& w, f3 P, f3 D) {
     return cost;
 }
 
-PT_DEV void wf_finalize(const WfParams& w, int li, f3 color, int seed) {
+PT_DEV void wf_finalize(const WfParams& w, int li, f3 color) {
     f3 acc = mk(0.0f, 0.0f, 0.0f);
     if (w.sample != 0) {
         const float4 c = w.rp.colors[li];
@@ -84,8 +85,41 @@ PT_DEV void wf_finalize(const WfParams& w, int li, f3 color, int seed) {
     }
     acc = running_mean(acc, color, w.sample);
     w.rp.colors[li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-    w.rp.rnds[li] = seed;
 }
+
+// The four path factors and the colour of pixel li in HBM, sP[field][li] x 12 B, behind the accessors shade_hit uses
+// (PathRegs, pt_device.hpp).  `flags` travels with the ray: bit f = field f was written in this sample -- a field that was
+// not is its initial value (1, or 0 for the colour) and costs no read; nothing is initialised when a sample starts.
+struct PathInHbm {
+    float* base;         // &sP[0][li]
+    size_t fstride;      // floats between fields
+    unsigned flags;
+    PT_DEV f3 get(int f, float init) const {
+        f3 v = mk(init, init, init);
+        if (flags & (1u << f)) {
+            const float* q = base + (size_t)f * fstride;
+            v = mk(q[0], q[1], q[2]);
+        }
+        return v;
+    }
+    PT_DEV void put(int f, f3 v) {
+        float* q = base + (size_t)f * fstride;
+        q[0] = v.x;
+        q[1] = v.y;
+        q[2] = v.z;
+        flags |= 1u << f;
+    }
+    PT_DEV f3 L() const { return get(kWfL, 1.f); }
+    PT_DEV f3 B() const { return get(kWfB, 1.f); }
+    PT_DEV f3 S() const { return get(kWfS, 1.f); }
+    PT_DEV f3 R() const { return get(kWfR, 1.f); }
+    PT_DEV f3 C() const { return get(kWfC, 0.f); }
+    PT_DEV void setL(f3 v) { put(kWfL, v); }
+    PT_DEV void setB(f3 v) { put(kWfB, v); }
+    PT_DEV void setS(f3 v) { put(kWfS, v); }
+    PT_DEV void setR(f3 v) { put(kWfR, v); }
+    PT_DEV void setC(f3 v) { put(kWfC, v); }
+};
 
 __global__ void __launch_bounds__(256) wf_generate(WfParams w) {
     __shared__ unsigned s_scratch[2 * 5];
@@ -103,15 +137,9 @@ __global__ void __launch_bounds__(256) wf_generate(WfParams w) {
         int seed = p.rnds[li];
         const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
         camera_get_ray(gid, p.cam, rnd1, rnd2, &P, &D);
-        if (p.iterations <= 0) {
-            wf_finalize(w, li, mk(0.0f, 0.0f, 0.0f), seed);
-        } else {
-            w.sC[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-            w.sD[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-            w.sE[li] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-            w.sF[li] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(seed));
-            cost = ray_cost_class(w, P, D);
-        }
+        p.rnds[li] = seed;
+        if (p.iterations <= 0) wf_finalize(w, li, mk(0.0f, 0.0f, 0.0f));
+        else cost = ray_cost_class(w, P, D);
     }
     if ((threadIdx.x & 63) == 0 && li < w.npix && p.stats) stat_add(p, 1, (unsigned long long)min(64, w.npix - li));
     const unsigned pos = block_reserve<2, 256>(cost, w.counters + kWfGenRow * kWfCounterStride, s_scratch);
@@ -156,9 +184,14 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
     // (the hang class of profiles/r02/v_*; tools/check_isa.py checks every instance)
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WorkCount wc;
-    // the grid only fills the chip: a block takes the trips block_base = blockIdx.x * RPB, + gridDim.x * RPB, ...
-    // (the nodes are staged once per block, not once per 1,024 rays)
-    for (unsigned block_base = blockIdx.x * RPB; block_base < n; block_base += gridDim.x * RPB) {
+    // the grid only fills the chip (the nodes are staged once per block, not once per trip); a block's first trip is
+    // block_base = blockIdx.x * RPB, every further one is fetched from a counter (word 5 / 6 of the bounce's row), so that
+    // a block whose rays were cheap takes over from one whose rays were not (static striding left 1.7 trips per block with
+    // nothing to balance them: profiles/r03/b_*)
+    __shared__ unsigned s_next_base;
+    unsigned block_base = blockIdx.x * RPB;
+    const unsigned first_dynamic = gridDim.x * RPB;
+    for (;;) {
         unsigned cbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(block_base + wave * kWfRaysPerWave));  // uniform per wave: next unassigned ray
         const unsigned cend = (unsigned)__builtin_amdgcn_readfirstlane((int)min(cbase + (unsigned)kWfRaysPerWave, n));
         if (cbase > cend) cbase = cend;
@@ -258,7 +291,10 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
             const unsigned r = k * BLOCK + threadIdx.x;
             if (cl[k] >= 0) w.q_cls[cl[k]][lds_base[cl[k]] + lds_cnt[(r >> 6) * 3 + cl[k]] + off[k]] = (int)(((unsigned)cost << 31) | (block_base + r));
         }
-        __syncthreads();            // lds_cls / lds_cnt are rewritten by the next trip
+        if (threadIdx.x == 0) s_next_base = first_dynamic + atomicAdd(&ctr[5 + cost], (unsigned)RPB);
+        __syncthreads();            // (also: lds_cls / lds_cnt are rewritten by the next trip)
+        block_base = s_next_base;
+        if (block_base >= n) break;
     }
 }
 
@@ -274,6 +310,7 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
     const unsigned i = blockIdx.x * kWfShadeBlock + threadIdx.x;
     int li = 0;
     int cost = -1;                                        // >= 0: the path continues with a ray of that cost class
+    unsigned flags = 0;
     f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
     if (i < n) {
         const unsigned e = (unsigned)w.q_cls[cls][i];
@@ -281,31 +318,25 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
         const unsigned pos = e & 0x7fffffffu;
         const float4 A = w.rsA[bounce & 1][c_in][pos], B = w.rsB[bounce & 1][c_in][pos];
         li = __float_as_int(B.z);
-        const float4 F = w.sF[li];
-        f3 color = mk(F.x, F.y, F.z);
-        const int sbits = __float_as_int(F.w);
-        int seed = sbits & 0x7fffffff;
-        bool inside = sbits < 0;
+        PathInHbm st;
+        st.base = w.sP + (size_t)li * 3;
+        st.fstride = (size_t)w.npix * 3;
+        st.flags = (unsigned)__float_as_int(B.w);
         if (cls == 2) {                                   // miss: black environment, prog.cl:367-376
-            wf_finalize(w, li, color, seed);
+            wf_finalize(w, li, st.C());
         } else {
             const float2 h = w.hit[c_in][pos];
-            const float4 C = w.sC[li], Dq = w.sD[li], E = w.sE[li];
             rP = mk(A.x, A.y, A.z);
             rD = mk(A.w, B.x, B.y);
-            PathRegs st;
-            st.fL = mk(C.x, C.y, C.z); st.fB = mk(C.w, Dq.x, Dq.y); st.fS = mk(Dq.z, Dq.w, E.x); st.fR = mk(E.y, E.z, E.w);
-            st.color = color;
+            int seed = p.rnds[li];
+            const int seed_in = seed;
+            bool inside = (st.flags & (unsigned)kWfInsideBit) != 0;
             shade_hit<false>(rP, rD, st, seed, inside, p, p.tris, p.meta, __float_as_int(h.y), h.x);
-            const f3 fL = st.fL, fB = st.fB, fS = st.fS, fR = st.fR;
-            color = st.color;
+            if (seed != seed_in) p.rnds[li] = seed;
             if (bounce + 1 >= p.iterations) {
-                wf_finalize(w, li, color, seed);
+                wf_finalize(w, li, st.C());
             } else {
-                w.sC[li] = make_float4(fL.x, fL.y, fL.z, fB.x);
-                w.sD[li] = make_float4(fB.y, fB.z, fS.x, fS.y);
-                w.sE[li] = make_float4(fS.z, fR.x, fR.y, fR.z);
-                w.sF[li] = make_float4(color.x, color.y, color.z, __int_as_float(seed | (inside ? (int)0x80000000 : 0)));
+                flags = (st.flags & ~(unsigned)kWfInsideBit) | (inside ? (unsigned)kWfInsideBit : 0u);
                 cost = ray_cost_class(w, rP, rD);
             }
         }
@@ -313,7 +344,7 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
     const unsigned npos = block_reserve<2, kWfShadeBlock>(cost, w.counters + wf_row(bounce + 1) * kWfCounterStride, s_scratch);
     if (cost >= 0) {
         w.rsA[(bounce + 1) & 1][cost][npos] = make_float4(rP.x, rP.y, rP.z, rD.x);
-        w.rsB[(bounce + 1) & 1][cost][npos] = make_float4(rD.y, rD.z, __int_as_float(li), 0.0f);
+        w.rsB[(bounce + 1) & 1][cost][npos] = make_float4(rD.y, rD.z, __int_as_float(li), __int_as_float((int)flags));
     }
 }
 

@@ -20,26 +20,50 @@ sys.path.insert(0, ".")
 from bench import kernel_source_sha  # noqa: E402
 
 key, out = sys.argv[1], sys.argv[2]
+wavefront = key.startswith("wavefront")
 vals, durs = defaultdict(list), []
-for d in sys.argv[3:]:
-    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "k_render" in r["Kernel_Name"]:
-                vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for f in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "k_render" in r["Kernel_Name"]:
-                durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+if wavefront:
+    # the wavefront variant: a "launch" is one sample pass = wf_generate + iterations x (wf_intersect + wf_shade); counters
+    # and kernel time are summed over all of them and divided by the number of passes (= wf_generate launches) of the run
+    tot, npass, tdur = defaultdict(float), defaultdict(int), defaultdict(float)
+    for d in sys.argv[3:]:
+        for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "wf_" in r["Kernel_Name"]:
+                    tot[(d, r["Counter_Name"])] += float(r["Counter_Value"])
+                    if "wf_generate" in r["Kernel_Name"]:
+                        npass[(d, r["Counter_Name"])] += 1
+        for f in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "wf_" in r["Kernel_Name"]:
+                    tdur[d] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+                    if "wf_generate" in r["Kernel_Name"]:
+                        npass[(d, "_trace")] += 1
+    for (d, cn), v in tot.items():
+        vals[cn].append(v / max(npass[(d, cn)], 1))
+    durs = [tdur[d] / max(npass[(d, "_trace")], 1) for d in tdur]
+else:
+    for d in sys.argv[3:]:
+        for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "k_render" in r["Kernel_Name"]:
+                    vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for f in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "k_render" in r["Kernel_Name"]:
+                    durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
 
 
 def steady(v):          # drop the first (warm-up) launch of every pass when there are several
+    if wavefront:
+        return sum(v) / len(v)
     return sum(v[1:]) / len(v[1:]) if len(v) > 1 else v[0]
 
 
 c = {k: steady(v) for k, v in vals.items()}
 dur = sorted(durs)[len(durs) // 2]
 entry = {
-    "kernel": "k_render", "launch_seconds_under_profiler": dur,
+    "kernel": "wf_generate + wf_intersect + wf_shade, one sample pass" if wavefront else "k_render", "launch_seconds_under_profiler": dur,
     "valu_insts_per_launch": c.get("SQ_INSTS_VALU"),
     "active_lane_fraction": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if "SQ_THREAD_CYCLES_VALU" in c else None,
     "shader_clock_hz": c["GRBM_GUI_ACTIVE"] / 8.0 / dur if "GRBM_GUI_ACTIVE" in c else 2.4e9,
