@@ -121,32 +121,91 @@ struct PathInHbm {
     PT_DEV void setC(f3 v) { put(kWfC, v); }
 };
 
-__global__ void __launch_bounds__(256) wf_generate(WfParams w) {
-    __shared__ unsigned s_scratch[2 * 5];
-    const int li = blockIdx.x * 256 + threadIdx.x;
+// The same for K items per thread (item k of every thread before item k + 1): ONE atomic per class and block, whatever K.
+// A returning atomic on one address completes at ~88 per microsecond on MI355X: wf_generate with one pixel per thread and
+// 256-thread blocks (8,100 blocks at 1080p, two counters) spent its whole 99 us waiting for them (profiles/r03/h_*).
+// scratch: NCLS * (K * WAVES + 1) words.
+template <int NCLS, int BLOCK, int K>
+PT_DEV void block_reserve_multi(const int (&cls)[K], unsigned (&pos)[K], unsigned* counters, unsigned* scratch) {
+    constexpr int WAVES = BLOCK / 64;
+    constexpr int ROW = K * WAVES + 1;
+    const unsigned wave = threadIdx.x >> 6;
+    const unsigned long long lt = lanemask_lt();
+    unsigned myoff[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        myoff[k] = 0;
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) {
+            const unsigned long long m = __ballot(cls[k] == c);
+            if ((threadIdx.x & 63) == 0) scratch[c * ROW + k * WAVES + wave] = (unsigned)__popcll(m);
+            if (cls[k] == c) myoff[k] = (unsigned)__popcll(m & lt);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NCLS) {
+        unsigned* row = scratch + threadIdx.x * ROW;
+        unsigned tot = 0;
+        for (int i = 0; i < K * WAVES; ++i) { const unsigned v = row[i]; row[i] = tot; tot += v; }
+        row[K * WAVES] = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        pos[k] = ~0u;
+        if (cls[k] >= 0 && cls[k] < NCLS) {
+            const unsigned* row = scratch + cls[k] * ROW;
+            pos[k] = row[K * WAVES] + row[k * WAVES + wave] + myoff[k];
+        }
+    }
+    __syncthreads();
+}
+
+constexpr int kWfGenBlock = 1024, kWfGenPerThread = 4;
+
+__global__ void __launch_bounds__(kWfGenBlock) wf_generate(WfParams w) {
+    __shared__ unsigned s_scratch[2 * (kWfGenPerThread * (kWfGenBlock / 64) + 1)];
     const RenderParams& p = w.rp;
     // rows >= 1 (bounces >= 1) are cleared here; row 0 (bounce 0, filled by THIS launch) is cleared by
     // a memset the host enqueues in front of the kernel
-    if (li >= kWfCounterStride && li < (p.iterations + 3) * kWfCounterStride) w.counters[li] = 0u;
-    int cost = -1;
-    f3 P = mk(0.f, 0.f, 0.f), D = mk(0.f, 0.f, 1.f);
-    if (li < w.npix) {
-        const int lrow = li / p.width, x = li - lrow * p.width;
-        const int grow = ((lrow / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (lrow % p.rows_per_block);
-        const int gid = grow * p.width + x;
-        int seed = p.rnds[li];
-        const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
-        camera_get_ray(gid, p.cam, rnd1, rnd2, &P, &D);
-        p.rnds[li] = seed;
-        if (p.iterations <= 0) wf_finalize(w, li, mk(0.0f, 0.0f, 0.0f));
-        else cost = ray_cost_class(w, P, D);
+    const int ci = blockIdx.x * kWfGenBlock + threadIdx.x;
+    if (ci >= kWfCounterStride && ci < (p.iterations + 3) * kWfCounterStride) w.counters[ci] = 0u;
+    int cost[kWfGenPerThread];
+    f3 P[kWfGenPerThread], D[kWfGenPerThread];
+    int lis[kWfGenPerThread];
+    unsigned live = 0;
+#pragma unroll
+    for (int k = 0; k < kWfGenPerThread; ++k) {
+        const int li = (blockIdx.x * kWfGenPerThread + k) * kWfGenBlock + threadIdx.x;
+        lis[k] = li;
+        cost[k] = -1;
+        P[k] = mk(0.f, 0.f, 0.f);
+        D[k] = mk(0.f, 0.f, 1.f);
+        if (li < w.npix) {
+            ++live;
+            const int lrow = li / p.width, x = li - lrow * p.width;
+            const int grow = ((lrow / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (lrow % p.rows_per_block);
+            const int gid = grow * p.width + x;
+            int seed = p.rnds[li];
+            const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+            camera_get_ray(gid, p.cam, rnd1, rnd2, &P[k], &D[k]);
+            p.rnds[li] = seed;
+            if (p.iterations <= 0) wf_finalize(w, li, mk(0.0f, 0.0f, 0.0f));
+            else cost[k] = ray_cost_class(w, P[k], D[k]);
+        }
     }
-    if ((threadIdx.x & 63) == 0 && li < w.npix && p.stats) stat_add(p, 1, (unsigned long long)min(64, w.npix - li));
-    const unsigned pos = block_reserve<2, 256>(cost, w.counters + kWfGenRow * kWfCounterStride, s_scratch);
-    if (cost >= 0) {
-        w.rsA[0][cost][pos] = make_float4(P.x, P.y, P.z, D.x);
-        w.rsB[0][cost][pos] = make_float4(D.y, D.z, __int_as_float(li), 0.0f);
+    if (p.stats) {
+        unsigned long long n = wave_sum((unsigned long long)live);
+        if ((threadIdx.x & 63) == 0 && n) stat_add(p, 1, n);
     }
+    unsigned pos[kWfGenPerThread];
+    block_reserve_multi<2, kWfGenBlock, kWfGenPerThread>(cost, pos, w.counters + kWfGenRow * kWfCounterStride, s_scratch);
+#pragma unroll
+    for (int k = 0; k < kWfGenPerThread; ++k)
+        if (cost[k] >= 0) {
+            w.rsA[0][cost[k]][pos[k]] = make_float4(P[k].x, P[k].y, P[k].z, D[k].x);
+            w.rsB[0][cost[k]][pos[k]] = make_float4(D[k].y, D[k].z, __int_as_float(lis[k]), 0.0f);
+        }
 }
 
 // Rays per wave: each wave owns a contiguous range of the bounce's ray stream (no global atomics
@@ -157,11 +216,12 @@ constexpr int kWfSuspendLanes = 48;     // 8 / 16 / 32 / 48 -> 749 / 752 / 763 /
 // Traversal with lane refill: a trip = while-while rounds until most lanes are done; a lane whose ray is
 // finished takes the next ray of the wave's range before the next trip (the next ray's 32 B are prefetched one
 // assignment ahead, so the switch costs no memory round trip); the stragglers simply carry on.
-template <int MODE, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
+// WPS = waves per SIMD the register budget is set for, RPW = rays per wave and trip (instances: launch_wf_intersect)
+template <int MODE, int BLOCK, int WPS, int RPW>
+__global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounce) {
     typedef typename StackOf<MODE>::type StackT;
     constexpr int WAVES = BLOCK / 64;
-    constexpr int RPB = WAVES * kWfRaysPerWave;          // rays per block and trip
+    constexpr int RPB = WAVES * RPW;                     // rays per block and trip
     constexpr int CHUNKS = RPB / 64;
     const RenderParams& p = w.rp;
     const int cost = blockIdx.y;
@@ -192,8 +252,8 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
     unsigned block_base = blockIdx.x * RPB;
     const unsigned first_dynamic = gridDim.x * RPB;
     for (;;) {
-        unsigned cbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(block_base + wave * kWfRaysPerWave));  // uniform per wave: next unassigned ray
-        const unsigned cend = (unsigned)__builtin_amdgcn_readfirstlane((int)min(cbase + (unsigned)kWfRaysPerWave, n));
+        unsigned cbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(block_base + wave * RPW));  // uniform per wave: next unassigned ray
+        const unsigned cend = (unsigned)__builtin_amdgcn_readfirstlane((int)min(cbase + (unsigned)RPW, n));
         if (cbase > cend) cbase = cend;
         Trav<MODE> tr;
         // the big-triangle list first, for the wave's whole range with every lane busy: the hit record of a ray
@@ -298,67 +358,86 @@ __global__ void __launch_bounds__(BLOCK) wf_intersect(WfParams w, int bounce) {
     }
 }
 
-constexpr int kWfShadeBlock = 1024;
+constexpr int kWfShadeBlock = 1024, kWfShadePerThread = 1;      // (two rays per thread: 100 -> 109 us per launch, profiles/r03/h_*)
 
 __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce) {
-    __shared__ unsigned s_scratch[2 * (kWfShadeBlock / 64 + 1)];
+    __shared__ unsigned s_scratch[2 * (kWfShadePerThread * (kWfShadeBlock / 64) + 1)];
     const RenderParams& p = w.rp;
     const int cls = blockIdx.y;
     unsigned* ctr = w.counters + wf_row(bounce) * kWfCounterStride;
     const unsigned n = ctr[2 + cls];
-    if (blockIdx.x * kWfShadeBlock >= n) return;          // whole block idle
-    const unsigned i = blockIdx.x * kWfShadeBlock + threadIdx.x;
-    int li = 0;
-    int cost = -1;                                        // >= 0: the path continues with a ray of that cost class
-    unsigned flags = 0;
-    f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
-    if (i < n) {
-        const unsigned e = (unsigned)w.q_cls[cls][i];
-        const int c_in = (int)(e >> 31);
-        const unsigned pos = e & 0x7fffffffu;
-        const float4 A = w.rsA[bounce & 1][c_in][pos], B = w.rsB[bounce & 1][c_in][pos];
-        li = __float_as_int(B.z);
-        PathInHbm st;
-        st.base = w.sP + (size_t)li * 3;
-        st.fstride = (size_t)w.npix * 3;
-        st.flags = (unsigned)__float_as_int(B.w);
-        if (cls == 2) {                                   // miss: black environment, prog.cl:367-376
-            wf_finalize(w, li, st.C());
-        } else {
-            const float2 h = w.hit[c_in][pos];
-            rP = mk(A.x, A.y, A.z);
-            rD = mk(A.w, B.x, B.y);
-            int seed = p.rnds[li];
-            const int seed_in = seed;
-            bool inside = (st.flags & (unsigned)kWfInsideBit) != 0;
-            shade_hit<false>(rP, rD, st, seed, inside, p, p.tris, p.meta, __float_as_int(h.y), h.x);
-            if (seed != seed_in) p.rnds[li] = seed;
-            if (bounce + 1 >= p.iterations) {
-                wf_finalize(w, li, st.C());
+    constexpr unsigned per_block = kWfShadeBlock * kWfShadePerThread;
+    if (blockIdx.x * per_block >= n) return;              // whole block idle
+    int li[kWfShadePerThread];
+    int cost[kWfShadePerThread];                          // >= 0: the path continues with a ray of that cost class
+    unsigned flags[kWfShadePerThread];
+    f3 rP[kWfShadePerThread], rD[kWfShadePerThread];
+#pragma unroll
+    for (int k = 0; k < kWfShadePerThread; ++k) {
+        const unsigned i = (blockIdx.x * kWfShadePerThread + k) * kWfShadeBlock + threadIdx.x;
+        li[k] = 0;
+        cost[k] = -1;
+        flags[k] = 0;
+        rP[k] = mk(0.f, 0.f, 0.f);
+        rD[k] = mk(0.f, 0.f, 1.f);
+        if (i < n) {
+            const unsigned e = (unsigned)w.q_cls[cls][i];
+            const int c_in = (int)(e >> 31);
+            const unsigned pos = e & 0x7fffffffu;
+            const float4 A = w.rsA[bounce & 1][c_in][pos], B = w.rsB[bounce & 1][c_in][pos];
+            li[k] = __float_as_int(B.z);
+            PathInHbm st;
+            st.base = w.sP + (size_t)li[k] * 3;
+            st.fstride = (size_t)w.npix * 3;
+            st.flags = (unsigned)__float_as_int(B.w);
+            if (cls == 2) {                                   // miss: black environment, prog.cl:367-376
+                wf_finalize(w, li[k], st.C());
             } else {
-                flags = (st.flags & ~(unsigned)kWfInsideBit) | (inside ? (unsigned)kWfInsideBit : 0u);
-                cost = ray_cost_class(w, rP, rD);
+                const float2 h = w.hit[c_in][pos];
+                rP[k] = mk(A.x, A.y, A.z);
+                rD[k] = mk(A.w, B.x, B.y);
+                int seed = p.rnds[li[k]];
+                const int seed_in = seed;
+                bool inside = (st.flags & (unsigned)kWfInsideBit) != 0;
+                shade_hit<false>(rP[k], rD[k], st, seed, inside, p, p.tris, p.meta, __float_as_int(h.y), h.x);
+                if (seed != seed_in) p.rnds[li[k]] = seed;
+                if (bounce + 1 >= p.iterations) {
+                    wf_finalize(w, li[k], st.C());
+                } else {
+                    flags[k] = (st.flags & ~(unsigned)kWfInsideBit) | (inside ? (unsigned)kWfInsideBit : 0u);
+                    cost[k] = ray_cost_class(w, rP[k], rD[k]);
+                }
             }
         }
     }
-    const unsigned npos = block_reserve<2, kWfShadeBlock>(cost, w.counters + wf_row(bounce + 1) * kWfCounterStride, s_scratch);
-    if (cost >= 0) {
-        w.rsA[(bounce + 1) & 1][cost][npos] = make_float4(rP.x, rP.y, rP.z, rD.x);
-        w.rsB[(bounce + 1) & 1][cost][npos] = make_float4(rD.y, rD.z, __int_as_float(li), __int_as_float((int)flags));
-    }
+    unsigned npos[kWfShadePerThread];
+    block_reserve_multi<2, kWfShadeBlock, kWfShadePerThread>(cost, npos, w.counters + wf_row(bounce + 1) * kWfCounterStride, s_scratch);
+#pragma unroll
+    for (int k = 0; k < kWfShadePerThread; ++k)
+        if (cost[k] >= 0) {
+            w.rsA[(bounce + 1) & 1][cost[k]][npos[k]] = make_float4(rP[k].x, rP[k].y, rP[k].z, rD[k].x);
+            w.rsB[(bounce + 1) & 1][cost[k]][npos[k]] = make_float4(rD[k].y, rD[k].z, __int_as_float(li[k]), __int_as_float((int)flags[k]));
+        }
 }
 
 hipError_t launch_wf_generate(const WfParams& w, hipStream_t stream) {
-    const int need = std::max(w.npix, (w.rp.iterations + 3) * kWfCounterStride);
-    hipLaunchKernelGGL(wf_generate, dim3((need + 255) / 256), dim3(256), 0, stream, w);
+    constexpr int per_block = kWfGenBlock * kWfGenPerThread;
+    const int blocks = std::max((w.npix + per_block - 1) / per_block, ((w.rp.iterations + 3) * kWfCounterStride + kWfGenBlock - 1) / kWfGenBlock);
+    hipLaunchKernelGGL(wf_generate, dim3(blocks), dim3(kWfGenBlock), 0, stream, w);
     return hipGetLastError();
 }
 
-template <int MODE, int BLOCK>
+template <int MODE, int BLOCK, int WPS, int RPW>
+static size_t wf_intersect_lds(const WfParams& w) {
+    constexpr int RPB = (BLOCK / 64) * RPW;
+    return traversal_lds_bytes(w.rp, BLOCK) + RPB + (RPB / 64) * 3 * 4 + 32;
+}
+
+template <int MODE, int BLOCK, int WPS, int RPW>
 static hipError_t launch_wf_intersect_t(const WfParams& w, int bounce, int resident_blocks, hipStream_t stream) {
-    constexpr int RPB = (BLOCK / 64) * kWfRaysPerWave;
-    const size_t lds = traversal_lds_bytes(w.rp, BLOCK) + RPB + (RPB / 64) * 3 * 4 + 32;
-    auto kern = wf_intersect<MODE, BLOCK>;
+    constexpr int RPB = (BLOCK / 64) * RPW;
+    const size_t lds = wf_intersect_lds<MODE, BLOCK, WPS, RPW>(w);
+    auto kern = wf_intersect<MODE, BLOCK, WPS, RPW>;
     static LdsMark mark;
     const hipError_t e = ensure_dynamic_lds((const void*)kern, mark, lds);
     if (e != hipSuccess) return e;
@@ -369,18 +448,23 @@ static hipError_t launch_wf_intersect_t(const WfParams& w, int bounce, int resid
 }
 
 hipError_t launch_wf_intersect(const WfParams& w, int bounce, int cu_count, hipStream_t stream) {
-    // grid: what is resident at once (per cost class row; the rows of a launch share the chip)
+    // grid: what is resident at once (per cost class row; the rows of a launch share the chip).  Register budgets as for
+    // k_render: whole tree in LDS -> two 768-thread workgroups per CU at 80 VGPRs (six waves per SIMD) where their LDS
+    // fits, else two of 512; nodes from global memory -> six / seven 256-thread workgroups per CU
     switch (w.rp.node_mode) {
-    case kNodesLds: return launch_wf_intersect_t<kNodesLds, 512>(w, bounce, cu_count * 2, stream);
-    case kNodesGlobal: return launch_wf_intersect_t<kNodesGlobal, 256>(w, bounce, cu_count * 8, stream);
-    case kNodesWide: return launch_wf_intersect_t<kNodesWide, 256>(w, bounce, cu_count * 8, stream);
-    case kNodesTreelet: return launch_wf_intersect_t<kNodesTreelet, 1024>(w, bounce, cu_count, stream);
+    case kNodesLds:
+        if (2 * (wf_intersect_lds<kNodesLds, kLdsBlockWide, kLdsWpsWide, 128>(w) + 512) <= 160 * 1024)
+            return launch_wf_intersect_t<kNodesLds, kLdsBlockWide, kLdsWpsWide, 128>(w, bounce, cu_count * 2, stream);
+        return launch_wf_intersect_t<kNodesLds, 512, 4, kWfRaysPerWave>(w, bounce, cu_count * 2, stream);
+    case kNodesGlobal: return launch_wf_intersect_t<kNodesGlobal, 256, 6, kWfRaysPerWave>(w, bounce, cu_count * 6, stream);
+    case kNodesWide: return launch_wf_intersect_t<kNodesWide, 256, 6, kWfRaysPerWave>(w, bounce, cu_count * 6, stream);
+    case kNodesTreelet: return launch_wf_intersect_t<kNodesTreelet, 1024, 4, kWfRaysPerWave>(w, bounce, cu_count, stream);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_wf_shade(const WfParams& w, int bounce, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_shade, dim3((w.npix + kWfShadeBlock - 1) / kWfShadeBlock, 3), dim3(kWfShadeBlock), 0, stream, w, bounce);
+    hipLaunchKernelGGL(wf_shade, dim3((w.npix + kWfShadeBlock * kWfShadePerThread - 1) / (kWfShadeBlock * kWfShadePerThread), 3), dim3(kWfShadeBlock), 0, stream, w, bounce);
     return hipGetLastError();
 }
 
