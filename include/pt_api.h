@@ -235,6 +235,8 @@ int pt_debug_scene_sizes(const pt_context* ctx, int64_t* ntris, int64_t* nmats, 
 int pt_debug_scene_copy(const pt_context* ctx, pt_triangle* tris, pt_material* mats, int32_t* obj_begin);
 /* the reference's traversal encounter rank of each triangle, in add order */
 int pt_debug_encounter_rank(const pt_context* ctx, int32_t* out, int64_t n);
+/* after a counting launch (option count_work = 1, pt_render): per 8x8 tile of the local frame, shader-clock cycles / 64 spent on it */
+int pt_debug_tile_cost(pt_context* ctx, uint32_t* out, int64_t n_tiles);
 /* frame assembly: out[gid] = index into the rank-major all-gather buffer (slab_stride pixels per rank) that
  * global pixel gid is read from -- the host statement of the de-interleave kernel's map (no device work) */
 int pt_debug_gather_index(int32_t width, int32_t height, int32_t world, int32_t rows_per_block, int64_t slab_stride, int64_t* out);

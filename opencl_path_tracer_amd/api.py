@@ -46,7 +46,7 @@ EXPORTS = [
     "pt_generate_rays", "pt_trace_rays", "pt_render", "pt_set_current_sample", "pt_get_current_sample", "pt_sync",
     "pt_local_pixel_count", "pt_local_pixel_ids", "pt_read_colors", "pt_read_rnds", "pt_read_rays",
     "pt_resolve_ldr", "pt_bind_framebuffer", "pt_device_colors", "pt_device_rnds", "pt_set_stream",
-    "pt_set_option", "pt_get_stat", "pt_debug_bvh_sizes", "pt_debug_bvh_copy", "pt_debug_wide_nodes", "pt_debug_encounter_rank",
+    "pt_set_option", "pt_get_stat", "pt_debug_bvh_sizes", "pt_debug_bvh_copy", "pt_debug_wide_nodes", "pt_debug_encounter_rank", "pt_debug_tile_cost",
     "pt_debug_scene_sizes", "pt_debug_scene_copy", "pt_debug_closest_hit",
     "pt_slab_pixel_count", "pt_frame_size", "pt_comm_unique_id", "pt_comm_init", "pt_gather_frame", "pt_device_frame", "pt_read_frame",
     "pt_write_pfm", "pt_write_ppm", "pt_image_write_pfm", "pt_image_write_ppm", "pt_debug_gather_index", "pt_debug_deinterleave",
@@ -112,6 +112,7 @@ def _load():
     sig("pt_debug_bvh_copy", C.c_int, vp, vp, vp, vp, vp)
     sig("pt_debug_wide_nodes", C.c_int, vp, vp, i64, C.POINTER(i64))
     sig("pt_debug_encounter_rank", C.c_int, vp, vp, i64)
+    sig("pt_debug_tile_cost", C.c_int, vp, vp, i64)
     sig("pt_debug_scene_sizes", C.c_int, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64))
     sig("pt_debug_scene_copy", C.c_int, vp, vp, vp, vp)
     sig("pt_debug_closest_hit", C.c_int, vp, vp, i64, vp, vp)
@@ -460,4 +461,12 @@ class Scene:
     def debug_encounter_rank(self, n):
         out = np.empty(n, dtype=np.int32)
         self._ck(LIB.pt_debug_encounter_rank(self._h, _ptr(out), n))
+        return out
+
+    def debug_tile_cost(self):
+        """After set_option("count_work", 1) + render(n): per 8x8 tile of the local frame, the shader-clock cycles / 64 its wave spent on it."""
+        local_rows = self.local_pixels // self.width
+        n = ((self.width + 7) // 8) * ((local_rows + 7) // 8)
+        out = np.empty(n, dtype=np.uint32)
+        self._ck(LIB.pt_debug_tile_cost(self._h, _ptr(out), n))
         return out

@@ -114,6 +114,7 @@ struct pt_context {
     int persistent = 1;   // 1: megakernel waves pull tiles from a counter (grid = what fits the chip)
     uint32_t* d_tile_counter = nullptr;
     uint32_t* d_tile_done = nullptr;
+    uint32_t* d_tile_cost = nullptr;   // count_work: per tile, cycles / 64 its waves spent on it in the last launch (pt_debug_tile_cost)
     int chunk_spp = -1;   // persistent megakernel work items: > 0 (pass, tile) items of that many samples, 0 whole
                           // tiles, -1 automatic (4 when the context has clearly more tiles than resident waves)
     int sah_visit_cost = 10;   // tenths of a triangle test (option sah_visit_cost)
@@ -1149,6 +1150,7 @@ void pt_destroy(pt_context* ctx) {
         if (ctx->d_stats) (void)hipFree(ctx->d_stats);
         if (ctx->d_tile_counter) (void)hipFree(ctx->d_tile_counter);
         if (ctx->d_tile_done) (void)hipFree(ctx->d_tile_done);
+        if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
         if (ctx->d_wf_state) (void)hipFree(ctx->d_wf_state);
         if (ctx->d_wf_queues) (void)hipFree(ctx->d_wf_queues);
         if (ctx->d_wf_counters) (void)hipFree(ctx->d_wf_counters);
@@ -1632,6 +1634,11 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
             p.chunk_spp = chunk;
         }
     }
+    if (lc.count_work && p.n_tiles > 0) {      // per-tile cost of this launch (pt_debug_tile_cost)
+        if (!ctx->d_tile_cost) PT_HIP(ctx, hipMalloc((void**)&ctx->d_tile_cost, sizeof(uint32_t) * (size_t)p.n_tiles));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, sizeof(uint32_t) * (size_t)p.n_tiles, ctx->stream));
+        p.tile_cost = ctx->d_tile_cost;
+    }
     EventPair* ep;
     if ((rc = time_begin(ctx, &ep)) != PT_OK) return rc;
     PT_HIP(ctx, launch_render_mega(p, lc, ctx->stream));
@@ -2049,6 +2056,19 @@ int pt_debug_scene_copy(const pt_context* ctx, pt_triangle* tris, pt_material* m
     if (tris && !ctx->tris.empty()) std::memcpy(tris, ctx->tris.data(), sizeof(pt_triangle) * ctx->tris.size());
     if (mats && !ctx->mats.empty()) std::memcpy(mats, ctx->mats.data(), sizeof(pt_material) * ctx->mats.size());
     if (obj_begin && !ctx->obj_begin.empty()) std::memcpy(obj_begin, ctx->obj_begin.data(), sizeof(int32_t) * ctx->obj_begin.size());
+    return PT_OK;
+}
+
+// counting launches (option count_work): per 8x8 tile of the local frame, the shader-clock cycles / 64 its wave(s) spent on it,
+// summed over the work items of the last pt_render call -- the latency a launch with one tile per wave ends on
+int pt_debug_tile_cost(pt_context* ctx, uint32_t* out, int64_t n) {
+    PT_NEED_DEVICE(ctx);
+    const int64_t n_tiles = (int64_t)((ctx->W + 7) / 8) * ((ctx->local_rows + 7) / 8);
+    if (!out || n != n_tiles) return fail(ctx, PT_EINVAL, "pt_debug_tile_cost: n must be the number of 8x8 tiles of the local frame");
+    if (!ctx->d_tile_cost) return fail(ctx, PT_EINVAL, "pt_debug_tile_cost: no counting launch yet (option count_work, then pt_render)");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(out, ctx->d_tile_cost, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

@@ -7,15 +7,18 @@
 // anyway).  A lane whose path ends regenerates its next camera ray in the same loop, so the
 // wave stays converged on "traverse -> shade" instead of idling until the longest path of
 // the wave is done.  The launch is persistent: waves pull (pass, tile) work items from a global
-// counter (k_render); rnds/colors travel through HBM once per pass of 4-8 samples (~7 B/sample).
+// counter (k_render); rnds/colors travel through HBM once per pass of 32-64 samples (~1.8 B/sample).
 //
-// Traversal (pt_device.hpp): own BVH2 (64-B nodes holding both child boxes, 48-B triangle
-// packets), near child first, far child pushed on a per-lane stack that lives in LDS
-// ([entry][lane], bank = lane: conflict-free).  Every workgroup stages BVH nodes in LDS, re-laid
-// out so that the planes a ray needs are picked by address: the whole tree when it fits (Cornell
-// box: 941 nodes = 60 KB, two 512-thread workgroups per CU), otherwise the top of the tree (the
-// "treelet": the ~900-1,100 nodes with the largest boxes, one 1,024-thread workgroup per CU);
-// packets and the rest of a large tree are read through L1/L2.
+// Traversal (pt_device.hpp): own BVH2 (64-B nodes holding both child boxes, 48-B triangle packets) or its
+// 4-wide quantised collapse; the biggest triangles (walls, floor ...) are kept out of the tree and tested
+// first from an LDS copy; near child first, far children on a per-lane stack in LDS ([entry][lane]).
+//   * whole tree fits LDS (Cornell box: 935 nodes x 56 B): every workgroup stages it, re-laid out so that the planes a ray
+//     needs are picked by address; two 768-thread workgroups per CU = six waves per SIMD at 80 VGPRs (two of 512 at
+//     128 VGPRs where the stacks leave no room, or where the launch has fewer tiles than that many waves);
+//   * larger trees: nodes (4-wide by default) and packets through L1 / L2, 256-thread workgroups, up to seven waves
+//     per SIMD at 72 VGPRs (LEAN: nothing recomputable is carried across a traversal, double-precision constants sit
+//     in scalar registers); optionally the top of the tree in LDS behind a generic pointer (`treelet`).
+// Every instance keeps its wave-uniform loop state in scalar registers; `make check-isa` verifies that in the ISA.
 #include "pt_device.hpp"
 
 
@@ -287,6 +290,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
         const int s_end = chained ? min(s_begin + p.chunk_spp, p.first_sample + p.nsamples) : p.first_sample + p.nsamples;
         const PixelId px = pixel_of_wave(p, tile);
         unsigned item_segs = 0;
+        const unsigned long long item_t0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         if (px.li >= 0) {
             if (SCHED == kSchedLockstep) render_pixel_lockstep<SPLIT, MODE, COUNT, kLean, kScalarK>(p, sv, stk, px, s_begin, s_end, &item_segs, &wc);
             else render_pixel_suspend<SPLIT, MODE, COUNT, kLean, kScalarK>(p, sv, stk, px, s_begin, s_end, &item_segs, &wc);
@@ -300,7 +304,11 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
         if (COUNT) {      // segment-steps the wave executed for this item = 64 x the busiest lane's segments
             unsigned mx = item_segs;
             for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_down(mx, off, 64));
-            item_lane_steps += (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)mx) * 64ull;
+            const unsigned mxs = (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
+            item_lane_steps += (unsigned long long)mxs * 64ull;
+            // what the tile cost THIS wave, in shader-clock cycles / 64 (the wave shares its SIMD with the others resident there:
+            // that is the latency a launch with one tile per wave ends on)
+            if (p.tile_cost && lane0) atomicAdd(&p.tile_cost[tile], (unsigned)((__builtin_amdgcn_s_memtime() - item_t0) >> 6));
         }
         if (chained) {                                           // ---- release this pass of the tile
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -462,7 +470,10 @@ static hipError_t launch_render_t(const RenderParams& p, const LaunchConfig& lc,
     return hipErrorInvalidValue;
 }
 
-// the split API traces one sample per launch: the two schedules coincide, one instance suffices
+// The split API traces one sample per launch: the two schedules coincide, one instance suffices.  (Round 3 tried a third
+// one for it -- a wave streaming through its tiles lane by lane, each lane moving on the moment its own path has ended:
+// 1,415 against 1,784 Msamples/s.  With one sample per pixel the camera rays of a tile traced TOGETHER are worth more than
+// the idle lanes cost: profiles/r03/i_*.)
 hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) { return launch_render_t<true, false, kSchedLockstep>(p, lc, stream); }
 hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
     if (lc.schedule == kSchedLockstep)

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
     // a block whose rays were cheap takes over from one whose rays were not (static striding left 1.7 trips per block with
     // nothing to balance them: profiles/r03/b_*)
     __shared__ unsigned s_next_base;
-    unsigned block_base = blockIdx.x * RPB;
+    unsigned block_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * RPB));
     const unsigned first_dynamic = gridDim.x * RPB;
     for (;;) {
         unsigned cbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(block_base + wave * RPW));  // uniform per wave: next unassigned ray
@@ -351,9 +351,14 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
             const unsigned r = k * BLOCK + threadIdx.x;
             if (cl[k] >= 0) w.q_cls[cl[k]][lds_base[cl[k]] + lds_cnt[(r >> 6) * 3 + cl[k]] + off[k]] = (int)(((unsigned)cost << 31) | (block_base + r));
         }
-        if (threadIdx.x == 0) s_next_base = first_dynamic + atomicAdd(&ctr[5 + cost], (unsigned)RPB);
+        if (wave == 0) {            // (the fetched range is wave-uniform state: through scalar registers, as everywhere)
+            unsigned t = 0;
+            if ((threadIdx.x & 63) == 0) t = atomicAdd(&ctr[5 + cost], (unsigned)RPB);
+            t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+            if ((threadIdx.x & 63) == 0) s_next_base = first_dynamic + t;
+        }
         __syncthreads();            // (also: lds_cls / lds_cnt are rewritten by the next trip)
-        block_base = s_next_base;
+        block_base = (unsigned)__builtin_amdgcn_readfirstlane((int)s_next_base);
         if (block_base >= n) break;
     }
 }
