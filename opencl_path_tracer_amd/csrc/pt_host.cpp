@@ -18,9 +18,13 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <numeric>
 #include <queue>
 #include <thread>
@@ -150,6 +154,12 @@ int fail(pt_context* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// threads of the host-side scene path (option build_threads; 0: the machine's, at most 16)
+int host_threads(const pt_context* ctx) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    return ctx->build_threads > 0 ? ctx->build_threads : (int)std::min(16u, std::max(1u, hw));
+}
+
 }  // namespace
 
 namespace ptamd {
@@ -189,6 +199,104 @@ namespace {
         if (!(ctx)->has_device)                                                             \
             return fail(ctx, PT_ENODEVICE, "context was created without a HIP device (host-only); no CPU render path exists"); \
     } while (0)
+
+// A small persistent pool for the host-side scene path: the threaded builders issue hundreds of short parallel regions
+// (a 1M-triangle SAH build: ~150 at the top of the tree), and spawning 15 threads for each cost more than the regions did.
+// One region at a time; a second caller (another context on another host thread) simply runs its region on fresh threads.
+class HostPool {
+public:
+    static HostPool& get() { static HostPool p; return p; }
+    // fn(k) for k in [0, chunks), on up to `threads` threads including the caller
+    template <class F>
+    void run(size_t chunks, int threads, F fn) {
+        if (chunks == 0) return;
+        if (threads <= 1 || chunks == 1) { for (size_t k = 0; k < chunks; ++k) fn(k); return; }
+        std::unique_lock<std::mutex> region(region_mu_, std::try_to_lock);
+        if (!region.owns_lock()) {                       // pool busy: plain threads
+            std::atomic<size_t> next(0);
+            auto work = [&]() { for (size_t k = next.fetch_add(1); k < chunks; k = next.fetch_add(1)) fn(k); };
+            std::vector<std::thread> th;
+            for (int t = 1; t < std::min<int>(threads, (int)chunks); ++t) th.emplace_back(work);
+            work();
+            for (std::thread& t : th) t.join();
+            return;
+        }
+        grow(std::min<int>(threads, (int)chunks) - 1);
+        std::function<void(size_t)> f = fn;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &f;
+            chunks_ = chunks;
+            next_.store(0);
+            helpers_wanted_ = std::min<int>(threads, (int)chunks) - 1;
+            helpers_in_ = 0;
+            helpers_done_ = 0;
+            ++generation_;
+        }
+        cv_.notify_all();
+        for (size_t k = next_.fetch_add(1); k < chunks; k = next_.fetch_add(1)) fn(k);
+        std::unique_lock<std::mutex> lk(mu_);
+        job_ = nullptr;                                  // no helper may start on this job any more
+        done_cv_.wait(lk, [&]() { return helpers_done_ == helpers_in_; });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread& t : workers_) t.join();
+    }
+
+private:
+    void grow(int n) {
+        while ((int)workers_.size() < n) workers_.emplace_back([this]() { loop(); });
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::function<void(size_t)>* job = nullptr;
+            size_t chunks = 0;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&]() { return stop_ || (generation_ != seen && job_ != nullptr && helpers_in_ < helpers_wanted_); });
+                if (stop_) return;
+                seen = generation_;
+                job = job_;
+                chunks = chunks_;
+                ++helpers_in_;
+            }
+            for (size_t k = next_.fetch_add(1); k < chunks; k = next_.fetch_add(1)) (*job)(k);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                ++helpers_done_;
+            }
+            done_cv_.notify_all();
+        }
+    }
+    std::mutex region_mu_, mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    std::function<void(size_t)>* job_ = nullptr;
+    size_t chunks_ = 0;
+    std::atomic<size_t> next_{0};
+    int helpers_wanted_ = 0, helpers_in_ = 0, helpers_done_ = 0;
+    unsigned long long generation_ = 0;
+    bool stop_ = false;
+};
+
+// fn(begin, end) over [0, n) on up to `threads` threads (element-wise work: any split gives the same result)
+template <class F>
+void parallel_for(size_t n, size_t grain, int threads, F fn) {
+    const size_t nt = std::min<size_t>((size_t)std::max(threads, 1), (n + grain - 1) / std::max<size_t>(grain, 1));
+    if (nt <= 1) { fn((size_t)0, n); return; }
+    const size_t per = (n + nt - 1) / nt;
+    HostPool::get().run(nt, (int)nt, [&](size_t k) {
+        const size_t b = k * per, e = std::min(n, b + per);
+        if (b < e) fn(b, e);
+    });
+}
+int host_threads(const pt_context* ctx);
 
 // rows owned by `rank`: r with (r / rb) % world == rank
 int32_t count_local_rows(int32_t H, int32_t rank, int32_t world, int32_t rb) {
@@ -374,32 +482,89 @@ struct BvhBuilder {
     }
 
     // Bounds of [lo, hi) and, unless the range becomes a leaf (returns false), its partition point.
-    bool split(size_t lo, size_t hi, int depth, Aabb* box, size_t* mid_out) {
+    // The partition is STABLE (both sides keep their order), through `scratch`: the arrangement of `prims` -- hence the
+    // packed triangle order -- is then the same however a range was split: serially, or, for the big ranges at the top of
+    // the tree, with bounds, bins and partition spread over `split_threads` threads (min / max / counts: any grouping
+    // gives the same bins).  1M triangles: the serial top of the tree was half of the threaded build's time.
+    std::unique_ptr<BuildPrim[]> scratch;   // as long as prims (uninitialised); a range only ever uses its own slice
+    size_t scratch_len = 0;
+    void need_scratch() {
+        if (scratch_len < prims.size()) { scratch.reset(new BuildPrim[prims.size()]); scratch_len = prims.size(); }
+    }
+    static constexpr int NB = 16;
+    struct Bins {
+        Aabb bb[3][NB];
+        int cnt[3][NB];
+        void reset() {
+            for (int a = 0; a < 3; ++a)
+                for (int k = 0; k < NB; ++k) { bb[a][k].reset(); cnt[a][k] = 0; }
+        }
+    };
+    static int bin_of(float c, float lo, float scale) {
+        int k = (int)((c - lo) * scale);
+        return std::min(std::max(k, 0), NB - 1);
+    }
+    bool split(size_t lo, size_t hi, int depth, Aabb* box, size_t* mid_out, int split_threads = 1) {
         const size_t n = hi - lo;
+        const int mt = (split_threads > 1 && n >= 65536) ? split_threads : 1;
         Aabb b, cb;
         b.reset();
         cb.reset();
-        for (size_t i = lo; i < hi; ++i) { b.grow(prims[i].box); cb.grow(prims[i].c); }
+        if (mt > 1) {
+            std::vector<Aabb> pb((size_t)mt), pc((size_t)mt);
+            for (int k = 0; k < mt; ++k) { pb[(size_t)k].reset(); pc[(size_t)k].reset(); }
+            std::atomic<int> slot(0);
+            parallel_for(n, 1 << 14, mt, [&](size_t cbeg, size_t cend) {
+                Aabb x, y;
+                x.reset();
+                y.reset();
+                for (size_t i = lo + cbeg; i < lo + cend; ++i) { x.grow(prims[i].box); y.grow(prims[i].c); }
+                const size_t sidx = (size_t)slot.fetch_add(1);
+                pb[sidx] = x;
+                pc[sidx] = y;
+            });
+            for (int k = 0; k < mt; ++k) { b.grow(pb[(size_t)k]); cb.grow(pc[(size_t)k]); }
+        } else {
+            for (size_t i = lo; i < hi; ++i) { b.grow(prims[i].box); cb.grow(prims[i].c); }
+        }
         *box = b;
         if (n <= 1) return false;
 
         // --- binned SAH over the three axes
-        constexpr int NB = 16;
+        float ext[3], scale[3];
+        for (int a = 0; a < 3; ++a) {
+            ext[a] = cb.hi[a] - cb.lo[a];
+            scale[a] = ext[a] > 0.f ? (float)NB / ext[a] : 0.f;
+        }
+        Bins bins;
+        bins.reset();
+        auto bin_range = [&](Bins& out, size_t ibeg, size_t iend) {
+            for (int a = 0; a < 3; ++a) {
+                if (!(ext[a] > 0.f)) continue;
+                for (size_t i = ibeg; i < iend; ++i) {
+                    const int k = bin_of(prims[i].c[a], cb.lo[a], scale[a]);
+                    out.bb[a][k].grow(prims[i].box);
+                    out.cnt[a][k]++;
+                }
+            }
+        };
+        if (mt > 1) {
+            std::vector<Bins> part((size_t)mt);
+            for (Bins& p : part) p.reset();
+            std::atomic<int> slot(0);
+            parallel_for(n, 1 << 14, mt, [&](size_t cbeg, size_t cend) { bin_range(part[(size_t)slot.fetch_add(1)], lo + cbeg, lo + cend); });
+            for (const Bins& p : part)
+                for (int a = 0; a < 3; ++a)
+                    for (int k = 0; k < NB; ++k) { bins.bb[a][k].grow(p.bb[a][k]); bins.cnt[a][k] += p.cnt[a][k]; }
+        } else {
+            bin_range(bins, lo, hi);
+        }
         float best_cost = std::numeric_limits<float>::infinity();
         int best_axis = -1, best_bin = -1;
         for (int a = 0; a < 3; ++a) {
-            float ext = cb.hi[a] - cb.lo[a];
-            if (!(ext > 0.f)) continue;
-            Aabb bb[NB];
-            int cnt[NB];
-            for (int k = 0; k < NB; ++k) { bb[k].reset(); cnt[k] = 0; }
-            float scale = (float)NB / ext;
-            for (size_t i = lo; i < hi; ++i) {
-                int k = (int)((prims[i].c[a] - cb.lo[a]) * scale);
-                k = std::min(std::max(k, 0), NB - 1);
-                bb[k].grow(prims[i].box);
-                cnt[k]++;
-            }
+            if (!(ext[a] > 0.f)) continue;
+            const Aabb* bb = bins.bb[a];
+            const int* cnt = bins.cnt[a];
             float la[NB], ra[NB];
             int lc[NB], rc[NB];
             Aabb acc;
@@ -422,14 +587,39 @@ struct BvhBuilder {
         size_t mid = lo;
         bool median = (best_axis < 0);
         if (!median) {
-            float ext = cb.hi[best_axis] - cb.lo[best_axis];
-            float scale = (float)NB / ext;
-            auto it = std::partition(prims.begin() + lo, prims.begin() + hi, [&](const BuildPrim& p) {
-                int k = (int)((p.c[best_axis] - cb.lo[best_axis]) * scale);
-                k = std::min(std::max(k, 0), NB - 1);
-                return k <= best_bin;
-            });
-            mid = (size_t)(it - prims.begin());
+            const float blo = cb.lo[best_axis], bsc = scale[best_axis];
+            const int ax = best_axis, bbin = best_bin;
+            auto goes_left = [=](const BuildPrim& p) { return bin_of(p.c[ax], blo, bsc) <= bbin; };
+            need_scratch();
+            if (mt > 1) {
+                std::vector<size_t> nl((size_t)mt + 1, 0), bounds_((size_t)mt + 1, 0);
+                const size_t per = (n + (size_t)mt - 1) / (size_t)mt;
+                for (int k = 0; k <= mt; ++k) bounds_[(size_t)k] = std::min(n, (size_t)k * per);
+                HostPool::get().run((size_t)mt, mt, [&](size_t k) {
+                    size_t c = 0;
+                    for (size_t i = lo + bounds_[k]; i < lo + bounds_[k + 1]; ++i) c += goes_left(prims[i]) ? 1 : 0;
+                    nl[k + 1] = c;
+                });
+                for (int k = 0; k < mt; ++k) nl[(size_t)k + 1] += nl[(size_t)k];       // left elements in front of chunk k
+                const size_t total_left = nl[(size_t)mt];
+                HostPool::get().run((size_t)mt, mt, [&](size_t k) {
+                    size_t l = lo + nl[k];
+                    size_t r = lo + total_left + (bounds_[k] - nl[k]);
+                    for (size_t i = lo + bounds_[k]; i < lo + bounds_[k + 1]; ++i) {
+                        if (goes_left(prims[i])) scratch[l++] = prims[i]; else scratch[r++] = prims[i];
+                    }
+                });
+                parallel_for(n, 1 << 14, mt, [&](size_t cbeg, size_t cend) { std::memcpy(&prims[lo + cbeg], &scratch[lo + cbeg], sizeof(BuildPrim) * (cend - cbeg)); });
+                mid = lo + total_left;
+            } else {
+                size_t w = lo, r = lo;
+                for (size_t i = lo; i < hi; ++i) {
+                    if (goes_left(prims[i])) { if (w != i) prims[w] = prims[i]; ++w; }
+                    else scratch[r++] = prims[i];
+                }
+                if (r > lo) std::memcpy(&prims[w], &scratch[lo], sizeof(BuildPrim) * (r - lo));
+                mid = w;
+            }
             size_t big = std::max(mid - lo, hi - mid);
             if (mid == lo || mid == hi || depth + 1 + need_levels(big) > kMaxDepth) median = true;
         }
@@ -486,78 +676,134 @@ struct BvhBuilder {
         int deepest = 0;
         Aabb box;
     };
-    Part split_top(std::vector<TopNode>& tops, std::vector<Task>& tasks, size_t grain, size_t lo, size_t hi, int depth) {
-        Part p;
-        if (hi - lo <= grain) {
+    // The top of the tree, level by level: the ranges of a level are independent, so while they are fewer than the threads
+    // each is split ON all threads (bounds, bins and partition in parallel), and once they are more, each BY one thread, side by
+    // side.  Ranges of at most `grain` primitives become tasks.  Which node gets which index in `tops` is irrelevant: splice()
+    // numbers the final nodes in preorder.
+    Part split_top(std::vector<TopNode>& tops, std::vector<Task>& tasks, size_t grain, size_t n, int threads) {
+        struct Open { size_t lo, hi; int depth; int32_t parent; int side; };      // parent -1: the root
+        struct Res { bool inner; Aabb box; size_t mid; };
+        Part root;
+        root.kind = 0;
+        root.v = 0;
+        auto place = [&](const Open& o, const Part& p) {
+            if (o.parent < 0) root = p;
+            else if (o.side == 0) tops[(size_t)o.parent].l = p;
+            else tops[(size_t)o.parent].r = p;
+        };
+        auto as_task = [&](const Open& o) {
+            Part p;
             p.kind = 2;
             p.v = (int32_t)tasks.size();
             tasks.emplace_back();
-            tasks.back().lo = lo;
-            tasks.back().hi = hi;
-            tasks.back().depth = depth;
-            return p;
+            tasks.back().lo = o.lo;
+            tasks.back().hi = o.hi;
+            tasks.back().depth = o.depth;
+            place(o, p);
+        };
+        std::vector<Open> level, nextl;
+        {
+            const Open o{0, n, 0, -1, 0};
+            if (n <= grain) as_task(o); else level.push_back(o);
         }
-        max_depth_seen = std::max(max_depth_seen, depth);
-        size_t mid;
-        if (!split(lo, hi, depth, &p.box, &mid)) {
-            p.kind = 0;
-            p.v = make_leaf(lo, hi);
-            return p;
+        while (!level.empty()) {
+            std::vector<Res> res(level.size());
+            if ((int)level.size() < threads) {
+                for (size_t i = 0; i < level.size(); ++i)
+                    res[i].inner = split(level[i].lo, level[i].hi, level[i].depth, &res[i].box, &res[i].mid, threads);
+            } else {
+                HostPool::get().run(level.size(), threads, [&](size_t i) {
+                    res[i].inner = split(level[i].lo, level[i].hi, level[i].depth, &res[i].box, &res[i].mid, 1);
+                });
+            }
+            nextl.clear();
+            for (size_t i = 0; i < level.size(); ++i) {
+                const Open& o = level[i];
+                max_depth_seen = std::max(max_depth_seen, o.depth);
+                Part p;
+                p.box = res[i].box;
+                if (!res[i].inner) {
+                    p.kind = 0;
+                    p.v = make_leaf(o.lo, o.hi);
+                    place(o, p);
+                    continue;
+                }
+                p.kind = 1;
+                p.v = (int32_t)tops.size();
+                tops.emplace_back();
+                place(o, p);
+                const Open kids[2] = {{o.lo, res[i].mid, o.depth + 1, p.v, 0}, {res[i].mid, o.hi, o.depth + 1, p.v, 1}};
+                for (const Open& k : kids) {
+                    if (k.hi - k.lo <= grain) as_task(k); else nextl.push_back(k);
+                }
+            }
+            level.swap(nextl);
         }
-        p.kind = 1;
-        p.v = (int32_t)tops.size();
-        tops.emplace_back();
-        const Part l = split_top(tops, tasks, grain, lo, mid, depth + 1);
-        const Part r = split_top(tops, tasks, grain, mid, hi, depth + 1);
-        tops[(size_t)p.v].l = l;
-        tops[(size_t)p.v].r = r;
-        return p;
+        return root;
     }
-    int32_t splice(const std::vector<TopNode>& tops, const std::vector<Task>& tasks, const Part& p, Aabb* box) {
+    // Preorder numbering of the final tree: top nodes are written as the walk passes them, a task's block is only given its
+    // place (task_off) -- the blocks are copied afterwards, side by side (copy_tasks).
+    int32_t splice(const std::vector<TopNode>& tops, const std::vector<Task>& tasks, std::vector<int32_t>& task_off, int32_t* next_index, const Part& p, Aabb* box) {
         if (p.kind == 0) { *box = p.box; return p.v; }
         if (p.kind == 2) {
             const Task& t = tasks[(size_t)p.v];
             *box = t.box;
             if (t.root < 0) return t.root;
-            const int32_t off = (int32_t)nodes.size();
-            for (Node64 nd : t.out) {
-                if (nd.left >= 0) nd.left += off;
-                if (nd.right >= 0) nd.right += off;
-                nodes.push_back(nd);
-            }
+            const int32_t off = *next_index;
+            task_off[(size_t)p.v] = off;
+            *next_index += (int32_t)t.out.size();
             return off + t.root;
         }
-        const int32_t me = (int32_t)nodes.size();
-        nodes.emplace_back();
+        const int32_t me = (*next_index)++;
         Aabb lb, rb;
-        const int32_t l = splice(tops, tasks, tops[(size_t)p.v].l, &lb);
-        const int32_t r = splice(tops, tasks, tops[(size_t)p.v].r, &rb);
+        const int32_t l = splice(tops, tasks, task_off, next_index, tops[(size_t)p.v].l, &lb);
+        const int32_t r = splice(tops, tasks, task_off, next_index, tops[(size_t)p.v].r, &rb);
+        if (nodes.size() < (size_t)*next_index) nodes.resize((size_t)*next_index);
         set_children(nodes[(size_t)me], l, r, lb, rb);
         Aabb b = lb;
         b.grow(rb);
         *box = b;
         return me;
     }
+    void copy_tasks(const std::vector<Task>& tasks, const std::vector<int32_t>& task_off, int threads) {
+        HostPool::get().run(tasks.size(), threads, [&](size_t i) {
+            const Task& t = tasks[i];
+            if (t.root < 0) return;
+            const int32_t off = task_off[i];
+            for (size_t k = 0; k < t.out.size(); ++k) {
+                Node64 nd = t.out[k];
+                if (nd.left >= 0) nd.left += off;
+                if (nd.right >= 0) nd.right += off;
+                nodes[(size_t)off + k] = nd;
+            }
+        });
+    }
     int32_t build_parallel(int threads, Aabb* box) {
         const size_t n = prims.size();
         const size_t grain = std::max<size_t>(4096, n / ((size_t)threads * 8));
         std::vector<TopNode> tops;
         std::vector<Task> tasks;
-        const Part root = split_top(tops, tasks, grain, 0, n, 0);
-        std::atomic<size_t> next(0);
-        auto work = [&]() {
-            for (size_t i = next.fetch_add(1); i < tasks.size(); i = next.fetch_add(1)) {
-                Task& t = tasks[i];
-                t.out.reserve(t.hi - t.lo);
-                t.root = build_into(t.out, &t.deepest, t.lo, t.hi, t.depth, &t.box);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int k = 1; k < threads; ++k) pool.emplace_back(work);
-        work();
-        for (std::thread& th : pool) th.join();
+        PhaseClock clk("sah build");
+        need_scratch();
+        const Part root = split_top(tops, tasks, grain, n, threads);
+        clk.lap("top of the tree");
+        HostPool::get().run(tasks.size(), threads, [&](size_t i) {
+            Task& t = tasks[i];
+            t.out.reserve(t.hi - t.lo);
+            t.root = build_into(t.out, &t.deepest, t.lo, t.hi, t.depth, &t.box);
+        });
+        clk.lap("subtrees");
         for (const Task& t : tasks) max_depth_seen = std::max(max_depth_seen, t.deepest);
-        return splice(tops, tasks, root, box);
+        std::vector<int32_t> task_off(tasks.size(), 0);
+        int32_t total = 0;
+        size_t upper = tops.size();
+        for (const Task& t : tasks) upper += t.out.size();
+        nodes.resize(upper);                                     // (all of them are written below)
+        const int32_t r = splice(tops, tasks, task_off, &total, root, box);
+        nodes.resize((size_t)total);
+        copy_tasks(tasks, task_off, threads);
+        clk.lap("splice");
+        return r;
     }
 };
 
@@ -578,15 +824,16 @@ Aabb padded_bounds(const pt_triangle& t) {
 
 // One build attempt.  Returns PT_OK and fills bld.
 void compute_cost_boxes_impl(pt_context* ctx);
+void compute_cost_boxes_from(pt_context* ctx, const Aabb* boxes);
 
-int build_attempt(pt_context* ctx, BvhBuilder& bld, const std::vector<BuildPrim>& prims, const std::vector<int32_t>& flat, int max_leaf, bool force_leaf) {
+int build_attempt(pt_context* ctx, BvhBuilder& bld, std::vector<BuildPrim>& prims, const std::vector<int32_t>& flat, int max_leaf, bool force_leaf) {
     bld = BvhBuilder();
-    bld.prims = prims;
+    bld.prims.swap(prims);         // (the caller has no further use for them)
     bld.max_leaf = max_leaf;
     bld.force_leaf = force_leaf;
     bld.visit_cost = (float)ctx->sah_visit_cost * 0.1f;
-    bld.nodes.reserve(prims.size());
-    bld.order.reserve(prims.size() + flat.size());
+    bld.nodes.reserve(bld.prims.size());
+    bld.order.reserve(bld.prims.size() + flat.size());
     bld.order = flat;            // the flat list comes first in packed order; leaf ranges start behind it
     bld.order_base = (int32_t)flat.size();
     // The root must be an interior node: wrap a leaf / an empty scene.
@@ -620,66 +867,104 @@ int build_attempt(pt_context* ctx, BvhBuilder& bld, const std::vector<BuildPrim>
 std::vector<int32_t> select_flat_list(const pt_context* ctx, std::vector<BuildPrim>& prims) {
     std::vector<int32_t> flat;
     if (ctx->flat_list > 0 && !prims.empty()) {
+        const int threads = host_threads(ctx);
         // only the `cand` biggest need to be in order (ties: add order), the others only need their common box
-        std::vector<float> area(prims.size());
-        for (size_t i = 0; i < prims.size(); ++i) area[i] = prims[i].box.half_area();
-        std::vector<size_t> by_area(prims.size());
-        std::iota(by_area.begin(), by_area.end(), (size_t)0);
-        const size_t cand = std::min<size_t>((size_t)ctx->flat_list, prims.size());
-        std::partial_sort(by_area.begin(), by_area.begin() + (std::ptrdiff_t)cand, by_area.end(),
-                          [&](size_t a, size_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); });
-        std::vector<Aabb> rest(cand + 1);             // rest[k] = box of by_area[k..]
+        const size_t n = prims.size();
+        std::vector<float> area(n);
+        parallel_for(n, 1 << 15, threads, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) area[i] = prims[i].box.half_area(); });
+        const size_t cand = std::min<size_t>((size_t)ctx->flat_list, n);
+        auto bigger = [&](size_t a, size_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); };
+        std::vector<size_t> top;                     // the cand biggest, in order: one pass with a small sorted buffer
+        top.reserve(cand + 1);
+        for (size_t i = 0; i < n; ++i) {
+            if (top.size() == cand && !bigger(i, top.back())) continue;
+            top.insert(std::upper_bound(top.begin(), top.end(), i, bigger), i);
+            if (top.size() > cand) top.pop_back();
+        }
+        std::vector<char> in_top(n, 0);
+        for (size_t k : top) in_top[k] = 1;
+        // box of everything that is not among them (min / max: any grouping gives the same box)
+        std::vector<Aabb> part((size_t)threads);
+        for (Aabb& p : part) p.reset();
+        {
+            std::atomic<int> slot(0);
+            parallel_for(n, 1 << 15, threads, [&](size_t b, size_t e) {
+                Aabb acc;
+                acc.reset();
+                for (size_t i = b; i < e; ++i)
+                    if (!in_top[i]) acc.grow(prims[i].box);
+                part[(size_t)slot.fetch_add(1)] = acc;
+            });
+        }
+        std::vector<Aabb> rest(cand + 1);             // rest[k] = box of top[k..] and all the others
         Aabb tail;
         tail.reset();
-        for (size_t k = prims.size(); k-- > cand;) tail.grow(prims[by_area[k]].box);
+        for (const Aabb& p : part) tail.grow(p);
         rest[cand] = tail;
-        for (size_t k = cand; k-- > 0;) { tail.grow(prims[by_area[k]].box); rest[k] = tail; }
+        for (size_t k = cand; k-- > 0;) { tail.grow(prims[top[k]].box); rest[k] = tail; }
         // the largest m such that each of the m biggest is >= 1/16 of the box around all the others
-        std::vector<char> is_flat(prims.size(), 0);
+        std::vector<char> is_flat(n, 0);
+        size_t n_flat = 0;
         for (size_t m = cand; m > 0; --m) {
-            const float smallest = prims[by_area[m - 1]].box.half_area(), others = rest[m].half_area();
+            const float smallest = prims[top[m - 1]].box.half_area(), others = rest[m].half_area();
             if (smallest >= others * (1.0f / 16.0f)) {
-                for (size_t k = 0; k < m; ++k) is_flat[by_area[k]] = 1;
+                for (size_t k = 0; k < m; ++k) is_flat[top[k]] = 1;
+                n_flat = m;
                 break;
             }
         }
-        std::vector<BuildPrim> kept;
-        kept.reserve(prims.size());
-        for (size_t i = 0; i < prims.size(); ++i) {
-            if (is_flat[i]) flat.push_back(prims[i].tri); else kept.push_back(prims[i]);      // add order within the list
+        if (n_flat > 0) {                             // take them out in place, add order kept on both sides
+            size_t w = 0;
+            for (size_t i = 0; i < n; ++i) {
+                if (is_flat[i]) flat.push_back(prims[i].tri);
+                else { if (w != i) prims[w] = prims[i]; ++w; }
+            }
+            prims.resize(w);
         }
-        prims.swap(kept);
     }
     return flat;
 }
 
 int build_and_pack(pt_context* ctx) {
+    PhaseClock clk("pt_upload_triangles");
     const size_t n = ctx->tris.size();
-    std::vector<BuildPrim> prims;
-    prims.reserve(n);
-    for (size_t i = 0; i < n; ++i) {
-        const pt_triangle& t = ctx->tris[i];
-        bool finite = true;
-        for (int a = 0; a < 3; ++a)
-            finite = finite && std::isfinite(t.r1.s[a]) && std::isfinite(t.r2.s[a]) && std::isfinite(t.r3.s[a]);
-        if (!finite) continue;  // cannot be hit (prog.cl:99-106 compares NaN) and has no box
-        BuildPrim p;
-        p.box = padded_bounds(t);
-        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.box.lo[a] + p.box.hi[a]);
-        p.tri = (int32_t)i;
-        prims.push_back(p);
+    const int threads = host_threads(ctx);
+    // padded boxes of ALL triangles once (the builder's primitives and the wavefront's cost boxes both come from them)
+    std::vector<Aabb> boxes(n);
+    std::vector<char> finite(n);
+    parallel_for(n, 1 << 14, threads, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const pt_triangle& t = ctx->tris[i];
+            bool f = true;
+            for (int a = 0; a < 3; ++a)
+                f = f && std::isfinite(t.r1.s[a]) && std::isfinite(t.r2.s[a]) && std::isfinite(t.r3.s[a]);
+            finite[i] = f ? 1 : 0;      // a non-finite triangle cannot be hit (prog.cl:99-106 compares NaN) and has no box
+            boxes[i] = padded_bounds(t);
+        }
+    });
+    std::vector<BuildPrim> prims(n);
+    parallel_for(n, 1 << 14, threads, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            BuildPrim& p = prims[i];
+            p.box = boxes[i];
+            for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.box.lo[a] + p.box.hi[a]);
+            p.tri = (int32_t)i;
+        }
+    });
+    {
+        size_t w = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (finite[i]) { if (w != i) prims[w] = prims[i]; ++w; }
+        prims.resize(w);
     }
-    // Big-triangle list: a triangle whose box is as large as the box of everything smaller than it (walls, a
-    // floor) sits near the root of any BVH, widens the boxes of the nodes above it, and every ray pays a
-    // node-phase / leaf-phase alternation to reach it.  Up to `flat_list` such triangles are kept OUT of the tree
-    // and tested first, by every lane, in a wave-uniform loop (full lane utilisation, scalar packet loads); their
-    // hits then prune the traversal of the rest from its first visit.  Candidates in order of box area: the m
-    // biggest qualify when each is >= 1/16 of the area of the box around all the other triangles (largest such m).
+    clk.lap("primitive boxes");
     std::vector<int32_t> flat = select_flat_list(ctx, prims);
+    clk.lap("big-triangle list");
     BvhBuilder bld;
     int rc = ctx->bvh_policy <= 1 ? build_attempt(ctx, bld, prims, flat, 4, false)
                                   : build_attempt(ctx, bld, prims, flat, ctx->bvh_policy == 2 ? 4 : 8, true);
     if (rc != PT_OK) return rc;
+    clk.lap("SAH build");
     ctx->n_flat = (int)flat.size();
     if (bld.max_depth_seen > kMaxDepth) return fail(ctx, PT_ESCENE, "internal: BVH deeper than the traversal stack");
     ctx->bvh_depth = bld.max_depth_seen;
@@ -690,47 +975,62 @@ int build_and_pack(pt_context* ctx) {
     ctx->meta.resize(std::max<size_t>(m, 1));
     std::memset(ctx->packets.data(), 0, sizeof(TriPacket) * ctx->packets.size());
     std::memset(ctx->meta.data(), 0, sizeof(TriMeta) * ctx->meta.size());
-    compute_cost_boxes_impl(ctx);
-    for (size_t k = 0; k < m; ++k) {
-        const pt_triangle& t = ctx->tris[ctx->orig[k]];
-        float* v = ctx->packets[k].v;
-        v[0] = t.r1.s[0]; v[1] = t.r1.s[1]; v[2] = t.r1.s[2];
-        v[3] = t.r2.s[0]; v[4] = t.r2.s[1]; v[5] = t.r2.s[2];
-        v[6] = t.r3.s[0]; v[7] = t.r3.s[1]; v[8] = t.r3.s[2];
-        v[9] = t.N.s[0]; v[10] = t.N.s[1]; v[11] = t.N.s[2];
-        ctx->meta[k].rank = ctx->enc_rank[ctx->orig[k]];
-        ctx->meta[k].mati = t.mati;
-    }
+    compute_cost_boxes_from(ctx, boxes.data());
+    clk.lap("cost boxes");
+    parallel_for(m, 1 << 14, threads, [&](size_t kb, size_t ke) {
+        for (size_t k = kb; k < ke; ++k) {
+            const pt_triangle& t = ctx->tris[ctx->orig[k]];
+            float* v = ctx->packets[k].v;
+            v[0] = t.r1.s[0]; v[1] = t.r1.s[1]; v[2] = t.r1.s[2];
+            v[3] = t.r2.s[0]; v[4] = t.r2.s[1]; v[5] = t.r2.s[2];
+            v[6] = t.r3.s[0]; v[7] = t.r3.s[1]; v[8] = t.r3.s[2];
+            v[9] = t.N.s[0]; v[10] = t.N.s[1]; v[11] = t.N.s[2];
+            ctx->meta[k].rank = ctx->enc_rank[ctx->orig[k]];
+            ctx->meta[k].mati = t.mati;
+        }
+    });
+    clk.lap("packets + meta");
     return PT_OK;
 }
 
 // bounding boxes of the complex objects (more than 16 triangles), for the wavefront cost classes
-void compute_cost_boxes_impl(pt_context* ctx) {
-    {
-        struct OB { Aabb b; size_t n; };
-        std::vector<OB> obs;
-        for (size_t o = 0; o < ctx->obj_begin.size(); ++o) {
-            const size_t lo = (size_t)ctx->obj_begin[o], hi = o + 1 < ctx->obj_begin.size() ? (size_t)ctx->obj_begin[o + 1] : ctx->tris.size();
-            if (hi - lo <= 16) continue;
-            OB ob;
-            ob.b.reset();
-            ob.n = hi - lo;
-            for (size_t i = lo; i < hi; ++i) ob.b.grow(padded_bounds(ctx->tris[i]));
-            if (std::isfinite(ob.b.half_area())) obs.push_back(ob);
-        }
-        std::sort(obs.begin(), obs.end(), [](const OB& x, const OB& y) { return x.n > y.n; });
-        while (obs.size() > (size_t)kWfMaxCostBoxes) {       // fold the smallest objects into one box
-            obs[obs.size() - 2].b.grow(obs.back().b);
-            obs[obs.size() - 2].n += obs.back().n;
-            obs.pop_back();
-        }
-        ctx->cost_boxes.clear();
-        for (const OB& ob : obs) {
-            for (int a = 0; a < 3; ++a) ctx->cost_boxes.push_back(ob.b.lo[a]);
-            for (int a = 0; a < 3; ++a) ctx->cost_boxes.push_back(ob.b.hi[a]);
-        }
+// boxes of the objects with more than 16 triangles (the wavefront variant's ray cost classes); `boxes` = the padded bounds of
+// every add-order triangle if the caller has them already
+void compute_cost_boxes_from(pt_context* ctx, const Aabb* boxes) {
+    struct OB { Aabb b; size_t n; };
+    std::vector<OB> obs;
+    const int threads = host_threads(ctx);
+    for (size_t o = 0; o < ctx->obj_begin.size(); ++o) {
+        const size_t lo = (size_t)ctx->obj_begin[o], hi = o + 1 < ctx->obj_begin.size() ? (size_t)ctx->obj_begin[o + 1] : ctx->tris.size();
+        if (hi - lo <= 16) continue;
+        OB ob;
+        ob.b.reset();
+        ob.n = hi - lo;
+        std::vector<Aabb> part((size_t)threads);          // (min / max: any grouping gives the same box)
+        for (Aabb& p : part) p.reset();
+        std::atomic<int> slot(0);
+        parallel_for(hi - lo, 1 << 15, threads, [&](size_t b, size_t e) {
+            Aabb acc;
+            acc.reset();
+            for (size_t i = lo + b; i < lo + e; ++i) acc.grow(boxes ? boxes[i] : padded_bounds(ctx->tris[i]));
+            part[(size_t)slot.fetch_add(1)] = acc;
+        });
+        for (const Aabb& p : part) ob.b.grow(p);
+        if (std::isfinite(ob.b.half_area())) obs.push_back(ob);
+    }
+    std::sort(obs.begin(), obs.end(), [](const OB& x, const OB& y) { return x.n > y.n; });
+    while (obs.size() > (size_t)kWfMaxCostBoxes) {       // fold the smallest objects into one box
+        obs[obs.size() - 2].b.grow(obs.back().b);
+        obs[obs.size() - 2].n += obs.back().n;
+        obs.pop_back();
+    }
+    ctx->cost_boxes.clear();
+    for (const OB& ob : obs) {
+        for (int a = 0; a < 3; ++a) ctx->cost_boxes.push_back(ob.b.lo[a]);
+        for (int a = 0; a < 3; ++a) ctx->cost_boxes.push_back(ob.b.hi[a]);
     }
 }
+void compute_cost_boxes_impl(pt_context* ctx) { compute_cost_boxes_from(ctx, nullptr); }
 
 // Stack entries a traversal of this tree needs: sentinel + one far child per level + the slot above the top
 // that Trav::node_step writes unconditionally (+ 2 spare), rounded to even.
@@ -854,7 +1154,9 @@ int plan_node_placement(pt_context* ctx) {
     ctx->nodes4.clear();
     ctx->wide_pending = 0;
     if (ctx->wide_nodes == 2 || (ctx->wide_nodes == 1 && !fits && ctx->treelet_nodes == 0)) {
-        if (!build_wide_nodes(ctx->nodes, &ctx->nodes4, &ctx->wide_pending)) ctx->nodes4.clear();
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int threads = ctx->build_threads > 0 ? ctx->build_threads : (int)std::min(16u, std::max(1u, hw));
+        if (!build_wide_nodes(ctx->nodes, &ctx->nodes4, &ctx->wide_pending, threads)) ctx->nodes4.clear();
     }
     return PT_OK;
 }
@@ -1426,7 +1728,9 @@ int pt_upload_triangles(pt_context* ctx) {
     ctx->bvh_on_device = 0;
     int rc = build_and_pack(ctx);
     if (rc != PT_OK) return rc;
+    PhaseClock clk("pt_upload_triangles");
     if ((rc = plan_node_placement(ctx)) != PT_OK) return rc;
+    clk.lap("node placement + 4-wide nodes");
     ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (ctx->has_device) {
         PT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1435,6 +1739,7 @@ int pt_upload_triangles(pt_context* ctx) {
         if ((rc = alloc_stack_overflow(ctx)) != PT_OK) return rc;
         if ((rc = upload_vec(ctx, &ctx->d_tris, ctx->packets.data(), sizeof(TriPacket) * ctx->packets.size())) != PT_OK) return rc;
         if ((rc = upload_vec(ctx, &ctx->d_meta, ctx->meta.data(), sizeof(TriMeta) * ctx->meta.size())) != PT_OK) return rc;
+        clk.lap("device allocations + copies");
     }
     ctx->tris_uploaded = true;
     return PT_OK;

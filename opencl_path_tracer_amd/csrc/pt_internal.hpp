@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -55,7 +58,7 @@ struct Node4q {
 static_assert(sizeof(Node4q) == 64, "Node4q must be 64 B");
 constexpr int32_t kWideNoChild = ~0;      // the leaf {packet 0, 1 triangle}: always present (an empty scene holds one all-zero packet)
 constexpr int kWideLdsEntries = 20;   // 20 x 4 B x 256 lanes = 20 KB per workgroup: seven workgroups per CU next to the big-triangle list
-bool build_wide_nodes(const std::vector<Node64>& bvh2, std::vector<Node4q>* out, int* max_pending);   // pt_wide.cpp
+bool build_wide_nodes(const std::vector<Node64>& bvh2, std::vector<Node4q>* out, int* max_pending, int threads);   // pt_wide.cpp
 
 // Where the traversal reads BVH nodes from (Trav<MODE> in pt_device.hpp)
 enum : int { kNodesLds = 0, kNodesGlobal = 1, kNodesTreelet = 2, kNodesWide = 3 };
@@ -199,6 +202,20 @@ inline hipError_t ensure_dynamic_lds(const void* kern, LdsMark& mark, size_t lds
     while (seen < lds_bytes && !mark.bytes[dev].compare_exchange_weak(seen, lds_bytes, std::memory_order_release)) {}
     return hipSuccess;
 }
+
+// PTAMD_TRACE=1: phase times of the host-side scene path on stderr (pt_add_obj, pt_upload_triangles; tools/obj_load_time.py)
+struct PhaseClock {
+    const char* who;
+    const bool on = std::getenv("PTAMD_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit PhaseClock(const char* w) : who(w) {}
+    void lap(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[%s] %-32s %8.1f ms\n", who, what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 // launchers (pt_kernels.hip, pt_wavefront.hip, pt_debug.hip); all asynchronous on `stream`
 int traversal_block(int node_mode, bool wide_lds_block);       // threads per workgroup of k_render

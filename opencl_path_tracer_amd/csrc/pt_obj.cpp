@@ -12,7 +12,7 @@
 //     rotate_y(yaw), scale, translate (main.cpp:598-606); one end_Obj per shape (main.cpp:615).
 // Deviations, all turning undefined behaviour of the reference into errors: a missing
 // Kn/Kk/Tp, a face without usemtl (material id -1) and an empty shape return PT_EIO.
-#include "pt_api.h"
+#include "pt_internal.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -207,18 +207,6 @@ void parallel_ranges(size_t n, size_t grain, F fn) {
     for (std::thread& t : th) t.join();
 }
 
-// PTAMD_TRACE=1: phase times of pt_add_obj on stderr (tools/obj_load_time.py)
-struct PhaseClock {
-    const bool on = std::getenv("PTAMD_TRACE") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    void lap(const char* what) {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[pt_add_obj] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
-
 }  // namespace
 
 extern "C" int pt_add_obj(pt_context* ctx, const char* file, const float pos[3], const float scale[3], float pitch, float yaw) {
@@ -227,7 +215,7 @@ extern "C" int pt_add_obj(pt_context* ctx, const char* file, const float pos[3],
     const std::string path(file);
     const std::string matpath = path.substr(0, path.find_last_of('/') + 1);   // main.cpp:553
     std::vector<char> buf;
-    PhaseClock clk;
+    ptamd::PhaseClock clk("pt_add_obj");
     if (!read_file(path, &buf)) return fail_ctx(ctx, PT_EIO, "cannot open OBJ file: " + path);
     clk.lap("read file");
 

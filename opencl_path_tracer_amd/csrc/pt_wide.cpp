@@ -8,9 +8,11 @@
 // here with the very fma the kernel decodes them with), the exact triangle test and the tie-break by encounter
 // rank decide the hit as before, so results stay bit-identical.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 #include "pt_internal.hpp"
 
@@ -84,81 +86,170 @@ bool quantise_axis(const Kid* kids, int n, int a, float* origin, int* biased_exp
 
 }  // namespace
 
-// Returns false when the tree cannot be expressed (non-finite boxes): the caller keeps the BVH2 path.
-// *max_pending = the most stack entries a traversal can hold when it visits an interior node: every ancestor may
-// have left all its other children on the stack.
-bool build_wide_nodes(const std::vector<Node64>& bvh2, std::vector<Node4q>* out, int* max_pending) {
-    out->clear();
-    *max_pending = 0;
-    if (bvh2.empty()) return false;
-    struct Work { int32_t src; int32_t dst; int pending; };
+namespace {
+
+struct Work { int32_t src; int32_t dst; int pending; };
+
+// One 4-wide node from BVH2 node `src`: its children (opened top-down), quantised.  Interior children are reported in
+// kid_src[] (their BVH2 node) with ref[k] left for the caller to fill; returns the number of children, or -1 when the
+// boxes cannot be quantised.
+int make_wide_node(const std::vector<Node64>& bvh2, int32_t src, Node4q* out, int32_t kid_src[4]) {
+    Kid kids[4];
+    int n = 0;
+    {
+        Kid two[2];
+        kids_of(bvh2[(size_t)src], two);
+        for (int k = 0; k < 2; ++k)
+            if (!empty_box(two[k])) kids[n++] = two[k];
+    }
+    // open the interior child with the largest box until there are four children
+    while (n < 4) {
+        int pick = -1;
+        double best = -1.0;
+        for (int k = 0; k < n; ++k)
+            if (kids[k].ref >= 0 && half_area(kids[k]) > best) { best = half_area(kids[k]); pick = k; }
+        if (pick < 0) break;
+        Kid two[2];
+        kids_of(bvh2[(size_t)kids[pick].ref], two);
+        int live = 0;
+        Kid keep[2];
+        for (int k = 0; k < 2; ++k)
+            if (!empty_box(two[k])) keep[live++] = two[k];
+        if (live == 0) { kids[pick] = kids[--n]; continue; }
+        kids[pick] = keep[0];
+        if (live == 2) kids[n++] = keep[1];
+    }
+    Node4q nd;
+    std::memset(&nd, 0, sizeof nd);
+    uint8_t qlo[3][4] = {}, qhi[3][4] = {};
+    int e[3] = {1, 1, 1};
+    if (n > 0) {
+        for (int a = 0; a < 3; ++a)
+            if (!quantise_axis(kids, n, a, &nd.origin[a], &e[a], qlo[a], qhi[a])) return -1;
+    }
+    for (int a = 0; a < 3; ++a) nd.exp[a] = (uint8_t)e[a];
+    nd.nchild = (uint8_t)n;
+    for (int k = 0; k < 4; ++k) {
+        kid_src[k] = -1;
+        if (k >= n) {                       // no child: an inverted box, which a ray can only "hit" through the widening of
+            nd.ref[k] = kWideNoChild;       // far exit distances, and a reference that is harmless then (packet 0 as a leaf)
+            for (int a = 0; a < 3; ++a) { qlo[a][k] = 255; qhi[a][k] = 0; }
+            continue;
+        }
+        if (kids[k].ref >= 0) kid_src[k] = kids[k].ref;      // interior: the caller numbers it
+        else nd.ref[k] = kids[k].ref;
+    }
+    for (int k = 0; k < 4; ++k) {
+        nd.qlo_x |= (uint32_t)qlo[0][k] << (8 * k);
+        nd.qhi_x |= (uint32_t)qhi[0][k] << (8 * k);
+        nd.qlo_y |= (uint32_t)qlo[1][k] << (8 * k);
+        nd.qhi_y |= (uint32_t)qhi[1][k] << (8 * k);
+        nd.qlo_z |= (uint32_t)qlo[2][k] << (8 * k);
+        nd.qhi_z |= (uint32_t)qhi[2][k] << (8 * k);
+    }
+    *out = nd;
+    return n;
+}
+
+// the subtree below one 4-wide node, depth first into `out` (indices local to `out`; the subtree's root is written to *root)
+bool collapse_subtree(const std::vector<Node64>& bvh2, const Work& top, Node4q* root, std::vector<Node4q>* out, int* max_pending) {
     std::vector<Work> todo;
-    out->emplace_back();
-    todo.push_back({0, 0, 0});
+    todo.push_back({top.src, -1, top.pending});          // dst -1 = *root
     while (!todo.empty()) {
         const Work w = todo.back();
         todo.pop_back();
         *max_pending = std::max(*max_pending, w.pending);
-        Kid kids[4];
-        int n = 0;
-        {
-            Kid two[2];
-            kids_of(bvh2[(size_t)w.src], two);
-            for (int k = 0; k < 2; ++k)
-                if (!empty_box(two[k])) kids[n++] = two[k];
-        }
-        // open the interior child with the largest box until there are four children
-        while (n < 4) {
-            int pick = -1;
-            double best = -1.0;
-            for (int k = 0; k < n; ++k)
-                if (kids[k].ref >= 0 && half_area(kids[k]) > best) { best = half_area(kids[k]); pick = k; }
-            if (pick < 0) break;
-            Kid two[2];
-            kids_of(bvh2[(size_t)kids[pick].ref], two);
-            int live = 0;
-            Kid keep[2];
-            for (int k = 0; k < 2; ++k)
-                if (!empty_box(two[k])) keep[live++] = two[k];
-            if (live == 0) { kids[pick] = kids[--n]; continue; }
-            kids[pick] = keep[0];
-            if (live == 2) kids[n++] = keep[1];
-        }
         Node4q nd;
-        std::memset(&nd, 0, sizeof nd);
-        uint8_t qlo[3][4] = {}, qhi[3][4] = {};
-        int e[3] = {1, 1, 1};
-        if (n > 0) {
-            for (int a = 0; a < 3; ++a)
-                if (!quantise_axis(kids, n, a, &nd.origin[a], &e[a], qlo[a], qhi[a])) return false;
-        }
-        for (int a = 0; a < 3; ++a) nd.exp[a] = (uint8_t)e[a];
-        nd.nchild = (uint8_t)n;
-        for (int k = 0; k < 4; ++k) {
-            if (k >= n) {                       // no child: an inverted box, which a ray can only "hit" through the widening of
-                nd.ref[k] = kWideNoChild;       // far exit distances, and a reference that is harmless then (packet 0 as a leaf)
-                for (int a = 0; a < 3; ++a) { qlo[a][k] = 255; qhi[a][k] = 0; }
-                continue;
-            }
-            if (kids[k].ref >= 0) {
+        int32_t kid_src[4];
+        const int n = make_wide_node(bvh2, w.src, &nd, kid_src);
+        if (n < 0) return false;
+        for (int k = 0; k < 4; ++k)
+            if (kid_src[k] >= 0) {
                 const int32_t dst = (int32_t)out->size();
                 out->emplace_back();
                 nd.ref[k] = dst;
-                todo.push_back({kids[k].ref, dst, w.pending + n - 1});
-            } else {
-                nd.ref[k] = kids[k].ref;
+                todo.push_back({kid_src[k], dst, w.pending + n - 1});
             }
-        }
-        for (int k = 0; k < 4; ++k) {
-            nd.qlo_x |= (uint32_t)qlo[0][k] << (8 * k);
-            nd.qhi_x |= (uint32_t)qhi[0][k] << (8 * k);
-            nd.qlo_y |= (uint32_t)qlo[1][k] << (8 * k);
-            nd.qhi_y |= (uint32_t)qhi[1][k] << (8 * k);
-            nd.qlo_z |= (uint32_t)qlo[2][k] << (8 * k);
-            nd.qhi_z |= (uint32_t)qhi[2][k] << (8 * k);
-        }
+        if (w.dst < 0) *root = nd; else (*out)[(size_t)w.dst] = nd;
+    }
+    return true;
+}
+
+}  // namespace
+
+// Returns false when the tree cannot be expressed (non-finite boxes): the caller keeps the BVH2 path.
+// *max_pending = the most stack entries a traversal can hold when it visits an interior node: every ancestor may
+// have left all its other children on the stack.
+// The top of the tree is collapsed breadth first (its nodes come first, level by level) until there are a few hundred
+// open subtrees; those are collapsed depth first on `threads` threads, each into a block of its own, and appended in a
+// fixed order -- the numbering does not depend on the number of threads.
+bool build_wide_nodes(const std::vector<Node64>& bvh2, std::vector<Node4q>* out, int* max_pending, int threads) {
+    out->clear();
+    *max_pending = 0;
+    if (bvh2.empty()) return false;
+    constexpr size_t kFrontier = 512;
+    std::vector<Work> frontier;      // FIFO
+    size_t head = 0;
+    out->emplace_back();
+    frontier.push_back({0, 0, 0});
+    while (head < frontier.size() && frontier.size() - head < kFrontier) {
+        const Work w = frontier[head++];
+        *max_pending = std::max(*max_pending, w.pending);
+        Node4q nd;
+        int32_t kid_src[4];
+        const int n = make_wide_node(bvh2, w.src, &nd, kid_src);
+        if (n < 0) return false;
+        for (int k = 0; k < 4; ++k)
+            if (kid_src[k] >= 0) {
+                const int32_t dst = (int32_t)out->size();
+                out->emplace_back();
+                nd.ref[k] = dst;
+                frontier.push_back({kid_src[k], dst, w.pending + n - 1});
+            }
         (*out)[(size_t)w.dst] = nd;
     }
+    const size_t n_tasks = frontier.size() - head;
+    if (n_tasks == 0) return true;
+    std::vector<std::vector<Node4q>> blocks(n_tasks);
+    std::vector<Node4q> roots(n_tasks);
+    std::vector<int> pend(n_tasks, 0);
+    std::atomic<size_t> next(0);
+    std::atomic<bool> ok(true);
+    auto work = [&]() {
+        for (size_t t = next.fetch_add(1); t < n_tasks; t = next.fetch_add(1))
+            if (!collapse_subtree(bvh2, frontier[head + t], &roots[t], &blocks[t], &pend[t])) ok.store(false);
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < std::max(1, std::min<int>(threads, (int)n_tasks)); ++k) pool.emplace_back(work);
+    work();
+    for (std::thread& th : pool) th.join();
+    if (!ok.load()) { out->clear(); return false; }
+    size_t total = out->size();
+    std::vector<size_t> base(n_tasks);
+    for (size_t t = 0; t < n_tasks; ++t) { base[t] = total; total += blocks[t].size(); }
+    out->resize(total);
+    auto place = [&](size_t t) {
+        const int32_t b = (int32_t)base[t];
+        Node4q r = roots[t];
+        for (int k = 0; k < 4; ++k)
+            if (r.ref[k] >= 0) r.ref[k] += b;
+        (*out)[(size_t)frontier[head + t].dst] = r;
+        for (size_t i = 0; i < blocks[t].size(); ++i) {
+            Node4q nd = blocks[t][i];
+            for (int k = 0; k < 4; ++k)
+                if (nd.ref[k] >= 0) nd.ref[k] += b;
+            (*out)[base[t] + i] = nd;
+        }
+    };
+    next.store(0);
+    auto work2 = [&]() {
+        for (size_t t = next.fetch_add(1); t < n_tasks; t = next.fetch_add(1)) place(t);
+    };
+    pool.clear();
+    for (int k = 1; k < std::max(1, std::min<int>(threads, (int)n_tasks)); ++k) pool.emplace_back(work2);
+    work2();
+    for (std::thread& th : pool) th.join();
+    for (size_t t = 0; t < n_tasks; ++t) *max_pending = std::max(*max_pending, pend[t]);
     return true;
 }
 
