@@ -1808,7 +1808,11 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
             if ((size_t)w * lc->lds_bytes + 1024 <= kLdsPerCu) { lc->waves_per_simd = w; break; }
     }
     lc->persistent_blocks = ctx->cu_count * std::max(1, 256 * lc->waves_per_simd / lc->block);
-    lc->schedule = ctx->schedule >= 0 ? ctx->schedule : (p.n_tiles >= 3 * ptamd_resident_waves(ctx, *lc) ? 1 : 0);
+    // ... and with few samples per launch: a lane has no next sample to start while the others finish, and lanes that run
+    // ahead give up the coherence of a tile's camera rays -- lockstep up to 4 samples per launch with the tree in LDS
+    // (render(1): 1,810 against 1,492 Msamples/s), for one sample otherwise (profiles/r03/q_*)
+    const bool few_samples = p.nsamples <= (p.node_mode == kNodesLds ? 4 : 1);
+    lc->schedule = ctx->schedule >= 0 ? ctx->schedule : (!few_samples && p.n_tiles >= 3 * ptamd_resident_waves(ctx, *lc) ? 1 : 0);
     ctx->last_lds_bytes = lc->lds_bytes;
     ctx->last_waves_per_simd = lc->waves_per_simd;
 }
