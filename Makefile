@@ -40,6 +40,21 @@ check-isa: build/isa/pt_kernels.s build/isa/pt_wavefront.s tools/check_isa.py
 	python3 tools/check_isa.py build/isa/pt_kernels.s build/isa/pt_wavefront.s > build/isa/check.log || { cat build/isa/check.log; exit 1; }
 	@tail -1 build/isa/check.log
 
+# Host-side scene path (pt_add_obj: parallel parse, threaded encounter ranks; pt_upload_triangles: thread pool, parallel SAH
+# top, splice, 4-wide collapse) under ThreadSanitizer and under AddressSanitizer + UBSan, on a generated 200k-triangle OBJ,
+# one context and then two at once.  CPU only (host-only contexts); the device objects are linked in unchanged.
+HOSTSRC := pt_host.cpp pt_obj.cpp pt_wide.cpp pt_image.cpp
+DEVOBJ  := build/pt_kernels.hip.o build/pt_wavefront.hip.o build/pt_debug.hip.o build/pt_lbvh.hip.o build/pt_comm.hip.o
+SANFLAGS := -O1 -g -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -Iinclude -I$(CSRC)
+sanitize-host: $(DEVOBJ)
+	@for san in thread address,undefined; do d=build/san_$$(echo $$san | tr , _); mkdir -p $$d; \
+	  for f in $(HOSTSRC); do $(HIPCC) $(SANFLAGS) -fsanitize=$$san -c -o $$d/$$f.o $(CSRC)/$$f || exit 1; done; \
+	  $(HIPCC) $(SANFLAGS) -fsanitize=$$san -shared -o $$d/libptamd_san.so $$(for f in $(HOSTSRC); do echo $$d/$$f.o; done) $(DEVOBJ) -ldl -lpthread || exit 1; \
+	  /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fsanitize=$$san -Iinclude -o $$d/host_stress tests/cpp/host_stress.cpp -L$$d -lptamd_san -Wl,-rpath,$$PWD/$$d -Wl,-rpath,/opt/rocm/lib || exit 1; \
+	  python3 -c "import sys; sys.path.insert(0, '.'); from opencl_path_tracer_amd import scenes; print(scenes.write_grid_mesh_obj(200000, '$$d', (40.0, -15.0, 25.0), (2.0, 2.0, 2.0), 10.0, 30.0)[0])" > $$d/obj_path.txt || exit 1; \
+	  echo "== -fsanitize=$$san"; ASAN_OPTIONS=detect_leaks=0 $$d/host_stress $$(cat $$d/obj_path.txt) 2>&1 | tee $$d/report.txt; \
+	  if grep -q "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error" $$d/report.txt; then echo "sanitizer findings in $$d/report.txt"; exit 1; fi; done
+
 tests/cpp/dropin: tests/cpp/dropin_main.cpp include/pt_scene.hpp include/pt_api.h $(PKG)/libptamd.so
 	g++ -O1 -std=c++14 -Iinclude -o $@ tests/cpp/dropin_main.cpp -L$(PKG) -lptamd -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -Wl,-rpath,/opt/rocm/lib
 
@@ -50,4 +65,4 @@ clean:
 	rm -rf $(PKG)/libptamd*.so tests/cpp/dropin build
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean ab ab-objs check-isa
+.PHONY: all oracle clean ab ab-objs check-isa sanitize-host

@@ -183,10 +183,30 @@ def main():
         torch.cuda.synchronize(dev)
 
     use_cabi = world > 1 and args.exchange == "cabi" and not args.rehearse_on_one_gpu
+    exchange_note = None
     if use_cabi:          # the library's own RCCL communicator; torch only carries the 128-byte id
-        box = [api.comm_unique_id() if rank == 0 else None]
+        # Every rank must take the same path: a rank that cannot bind RCCL / create the communicator says so, the flags are
+        # reduced, and if ANY rank failed ALL ranks use torch's all-gather instead -- loudly: stderr, and "exchange" /
+        # "exchange_note" in the JSON line say which path produced the number.
+        ok, why = 1, ""
+        try:
+            box = [api.comm_unique_id() if rank == 0 else None]
+        except api.PtError as e:
+            box, ok, why = [None], 0, "pt_comm_unique_id: %s" % e
         dist.broadcast_object_list(box, src=0)
-        sc.comm_init(box[0])
+        if box[0] is None:
+            ok, why = 0, why or "rank 0 could not create a communicator id"
+        if ok:
+            try:
+                sc.comm_init(box[0])
+            except api.PtError as e:
+                ok, why = 0, "pt_comm_init: %s" % e
+        flag = torch.tensor([ok], dtype=torch.int32, device=comm_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            use_cabi = False
+            exchange_note = "C-ABI exchange unavailable (%s): torch.distributed all_gather_into_tensor used instead" % (why or "another rank failed")
+            print("[bench] rank %d: %s" % (rank, exchange_note), file=sys.stderr, flush=True)
 
     def exchange():
         if use_cabi:
@@ -269,6 +289,8 @@ def main():
             "config": {"workload": "Cornell box (12 wall/lamp triangles + 2 tessellated spheres = 1,932 triangles), "
                                    "%dx%d, %d bounces, %d spp (%d steps x %d spp)" % (W, H, B, total_spp, args.steps, args.spp_per_step),
                        "parallelism": "tiles%d" % world, "rows_per_block": ROWS_PER_BLOCK,
+                       "exchange": None if world == 1 else ("pt_gather_frame (ncclAllGather through the C ABI)" if use_cabi else "torch.distributed all_gather_into_tensor"),
+                       "exchange_note": exchange_note,
                        "variant": "megakernel" if args.variant == 0 else "wavefront",
                        "kernel": "k_render (fused gen_ray+trace_ray, persistent per pixel)" if args.variant == 0 else "wf_intersect (+wf_generate, wf_shade)"},
             "mean_path_segments": dbar, "msegments_per_s": segs / dt / 1e6, "radiance_checksum": checksum,

@@ -72,9 +72,11 @@ constexpr int kMaxDepth = 30;      // builder guarantees depth <= kMaxDepth
 constexpr int kStatRows = 256;     // statistics counters are spread over this many rows of kStatCols
 constexpr int kStatCols = 16;
 // k_render instances whose register budget is set for this many waves per SIMD or more carry nothing across a traversal
-// that can be recomputed or fetched (LEAN, pt_kernels.hip) -- A/B switch: 8 = never
+// that can be recomputed or fetched (LEAN, pt_kernels.hip) -- A/B switch: 8 = never.  7: at 80 VGPRs (six waves) the two
+// forms measure the same (2,347 / 2,354 on the Cornell box, 787 / 794 on MESH-100k, profiles/r03/r_*), and the plain one
+// leaves the frame buffer alone until the end of a pass.
 #ifndef PT_LEAN_FROM_WPS
-#define PT_LEAN_FROM_WPS 6
+#define PT_LEAN_FROM_WPS 7
 #endif
 constexpr int kLeanFromWps = PT_LEAN_FROM_WPS;
 // The k_render instances for a tree staged whole in LDS (two workgroups per CU either way): 2 x 768 threads at an 80-VGPR
