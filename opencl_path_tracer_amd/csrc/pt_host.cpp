@@ -125,6 +125,7 @@ struct pt_context {
     int flat_list = 16;        // at most this many big triangles go to the flat list (option flat_list; 0: none)
     int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
     int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 24)
+    int lbvh_ploc = 16;     // device-built trees: PLOC search radius (8 / 16 / 32); 0: Karras' radix tree over the Morton codes
     int lbvh_cluster = 64;  // device-built trees: the top above clusters of this many triangles is rebuilt with the host SAH (0: not)
     int build_threads = 0; // host SAH builder: threads (0: the machine's, at most 16); the tree is the same for any number
     int wide_nodes = 1;    // 4-wide quantised nodes: 0 never, 1 for trees that do not fit LDS, 2 for every tree (tests)
@@ -1619,15 +1620,28 @@ static bool sah_top_rebuild(pt_context* ctx, int cluster) {
 // bvh_policy 4: build the tree on the device (pt_lbvh.hip); host copies are kept for the debug getters
 static int build_on_device(pt_context* ctx, bool* done) {
     *done = false;
+    PhaseClock clk("pt_upload_triangles/device");
     const int n = (int)ctx->tris.size();
     if (!ctx->has_device || n <= 2 * kMaxLeaf) return PT_OK;
-    for (const pt_triangle& t : ctx->tris)
-        for (int a = 0; a < 3; ++a)
-            if (!std::isfinite(t.r1.s[a]) || !std::isfinite(t.r2.s[a]) || !std::isfinite(t.r3.s[a])) return PT_OK;   // host path handles those
+    {
+        std::atomic<bool> all_finite(true);
+        parallel_for((size_t)n, 1 << 14, host_threads(ctx), [&](size_t b, size_t e) {
+            bool ok = true;
+            for (size_t i = b; i < e && ok; ++i) {
+                const pt_triangle& t = ctx->tris[i];
+                for (int a = 0; a < 3; ++a) ok = ok && std::isfinite(t.r1.s[a]) && std::isfinite(t.r2.s[a]) && std::isfinite(t.r3.s[a]);
+            }
+            if (!ok) all_finite.store(false);
+        });
+        if (!all_finite.load()) return PT_OK;   // host path handles those
+    }
     PT_HIP(ctx, hipSetDevice(ctx->device));
     // the big-triangle list is chosen on the host (one pass over the boxes); the device builds the tree of the rest
+    const int threads = host_threads(ctx);
     std::vector<BuildPrim> prims((size_t)n);
-    for (int i = 0; i < n; ++i) { prims[(size_t)i].box = padded_bounds(ctx->tris[(size_t)i]); prims[(size_t)i].tri = i; }
+    parallel_for((size_t)n, 1 << 14, threads, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) { prims[i].box = padded_bounds(ctx->tris[i]); prims[i].tri = (int32_t)i; }
+    });
     const std::vector<int32_t> flat = select_flat_list(ctx, prims);
     const int nf = (int)flat.size(), ns = n - nf;
     if (ns <= 2 * kMaxLeaf) return PT_OK;
@@ -1636,15 +1650,24 @@ static int build_on_device(pt_context* ctx, bool* done) {
     const pt_triangle* b_tris = ctx->tris.data();
     const int32_t* b_rank = ctx->enc_rank.data();
     if (nf > 0) {
-        sub_tris.reserve((size_t)ns);
-        sub_rank.reserve((size_t)ns);
-        sub_orig.reserve((size_t)ns);
-        for (const BuildPrim& bp : prims) { sub_tris.push_back(ctx->tris[(size_t)bp.tri]); sub_rank.push_back(ctx->enc_rank[(size_t)bp.tri]); sub_orig.push_back(bp.tri); }
+        sub_tris.resize((size_t)ns);
+        sub_rank.resize((size_t)ns);
+        sub_orig.resize((size_t)ns);
+        parallel_for((size_t)ns, 1 << 14, threads, [&](size_t b, size_t e) {
+            for (size_t k = b; k < e; ++k) {
+                const int32_t t = prims[k].tri;
+                sub_tris[k] = ctx->tris[(size_t)t];
+                sub_rank[k] = ctx->enc_rank[(size_t)t];
+                sub_orig[k] = t;
+            }
+        });
         b_tris = sub_tris.data();
         b_rank = sub_rank.data();
     }
+    clk.lap("boxes + big-triangle list + gather");
     LbvhResult r;
-    PT_HIP(ctx, lbvh_build(b_tris, b_rank, ns, ctx->stream, &r));
+    PT_HIP(ctx, lbvh_build(b_tris, b_rank, ns, ctx->lbvh_ploc, ctx->stream, &r));
+    clk.lap("lbvh_build");
     auto drop = [&]() { (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta); (void)hipFree(r.d_orig); };
     if (r.depth + 5 > kStackEntries) {          // deeper than the traversal stack: let the host builder do it
         drop();
@@ -1676,14 +1699,22 @@ static int build_on_device(pt_context* ctx, bool* done) {
             ctx->meta[(size_t)k].mati = t.mati;
             ctx->orig[(size_t)k] = flat[(size_t)k];
         }
-        for (int k = nf; k < n; ++k) ctx->orig[(size_t)k] = sub_orig[(size_t)ctx->orig[(size_t)k]];
-        for (Node64& nd : ctx->nodes) {
-            if (nd.left < 0) nd.left -= nf << 3;
-            if (nd.right < 0) nd.right -= nf << 3;
-        }
+        parallel_for((size_t)(n - nf), 1 << 15, threads, [&](size_t b, size_t e) {
+            for (size_t k = (size_t)nf + b; k < (size_t)nf + e; ++k) ctx->orig[k] = sub_orig[(size_t)ctx->orig[k]];
+        });
+        parallel_for(ctx->nodes.size(), 1 << 15, threads, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                Node64& nd = ctx->nodes[i];
+                if (nd.left < 0) nd.left -= nf << 3;
+                if (nd.right < 0) nd.right -= nf << 3;
+            }
+        });
     }
+    clk.lap("download + list in front");
     const bool retopped = sah_top_rebuild(ctx, ctx->lbvh_cluster);
+    clk.lap("SAH top over clusters");
     int rc = plan_node_placement(ctx);
+    clk.lap("node placement + 4-wide nodes");
     if (rc != PT_OK) { drop(); return rc; }
     if (retopped) ctx->bvh_depth = ctx->interior_depth + 1;
     if (nf > 0 || retopped) {     // recomposed on the host: replace the builder's device arrays
@@ -1702,6 +1733,7 @@ static int build_on_device(pt_context* ctx, bool* done) {
     }
     if ((rc = upload_vec(ctx, &ctx->d_nodes4, ctx->nodes4.data(), sizeof(Node4q) * ctx->nodes4.size())) != PT_OK) return rc;
     if ((rc = alloc_stack_overflow(ctx)) != PT_OK) return rc;
+    clk.lap("uploads");
     *done = true;
     return PT_OK;
 }
@@ -2187,6 +2219,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "waves_per_simd") {
         if (value != -1 && (value < 4 || value > 8)) return fail(ctx, PT_EINVAL, "waves_per_simd: -1 automatic (at most 7), 4..8 (kernels that read nodes from global memory)");
         ctx->waves_per_simd = (int)value;
+    } else if (k == "lbvh_ploc") {
+        if (value != 0 && value != 8 && value != 16 && value != 32) return fail(ctx, PT_EINVAL, "lbvh_ploc: 0 (radix tree), 8, 16 or 32 (PLOC search radius)");
+        ctx->lbvh_ploc = (int)value;
     } else if (k == "lds_block") {
         if (value != -1 && value != kLdsBlockBase && value != kLdsBlockWide) return fail(ctx, PT_EINVAL, "lds_block: -1 automatic, 512 or 768");
         ctx->lds_block = (int)value;

@@ -188,18 +188,178 @@ __global__ void __launch_bounds__(256) k_fit(const unsigned long long* keys, int
     }
 }
 
-// a radix node survives as an interior node of the output iff it covers more than kMaxLeaf triangles
+// ---- PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) in place of the radix tree: the Morton order is
+// only used to find CANDIDATES -- every cluster looks R positions to either side for the partner with which it makes the
+// smallest box, mutual choices merge, the survivors close ranks, repeat until one cluster is left.  Splits therefore follow
+// box AREA, not bit positions of a space-filling curve: a Morton LBVH of the height-field meshes renders at 0.44-0.6x of the
+// SAH tree's rate (curve discontinuities put far-apart triangles under one low node), this at ~0.8-0.9x.
+// Internal nodes are numbered downwards from n - 2 in creation order, so the last merge -- the root -- is node 0.
+__device__ __forceinline__ float union_half_area(const Box& a, const Box& b) {
+    const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+    const float dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+    const float dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// nearest neighbour of cluster i among [i - R, i + R]: smallest union area; ties by the pair (min index, max index), which
+// is symmetric -- the globally smallest pair always chooses each other, so every round merges at least one pair
+template <int R>
+__global__ void __launch_bounds__(256) k_ploc_nn(const Box* cbox, int m, int* nn) {
+    __shared__ Box tile[256 + 2 * R];
+    const int base = blockIdx.x * 256 - R;
+    for (int t = threadIdx.x; t < 256 + 2 * R; t += 256) {
+        const int j = base + t;
+        if (j >= 0 && j < m) tile[t] = cbox[j];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const Box me = tile[threadIdx.x + R];
+    float best = __builtin_inff();
+    int bj = -1;
+    for (int d = -R; d <= R; ++d) {
+        const int j = i + d;
+        if (d == 0 || j < 0 || j >= m) continue;
+        const float c = union_half_area(me, tile[threadIdx.x + R + d]);
+        bool better = c < best;
+        if (c == best && bj >= 0) {
+            const int a0 = min(i, j), a1 = max(i, j), b0 = min(i, bj), b1 = max(i, bj);
+            better = a0 < b0 || (a0 == b0 && a1 < b1);
+        }
+        if (better) { best = c; bj = j; }
+    }
+    nn[i] = bj;
+}
+
+// leader[i] = 1: i and nn[i] chose each other and i is the lower one (it creates the node); keep[i] = 0 for the upper one
+__global__ void __launch_bounds__(256) k_ploc_mark(const int* nn, int m, int* leader, int* keep) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int j = nn[i];
+    const bool mutual = j >= 0 && nn[j] == i;
+    leader[i] = (mutual && i < j) ? 1 : 0;
+    keep[i] = (mutual && i > j) ? 0 : 1;
+}
+
+__global__ void __launch_bounds__(256) k_ploc_apply(const int* cid, const Box* cbox, const int* nn, const int* leader, const int* leader_scan,
+                                                    const int* keep, const int* keep_scan, int m, int next_id /* index of this round's first new node */,
+                                                    RadixNode* nodes, Box* node_boxes, int* parent_of_internal, int* parent_of_leaf,
+                                                    int* cid_out, Box* cbox_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m || !keep[i]) return;
+    const int p = keep_scan[i];
+    if (!leader[i]) {
+        cid_out[p] = cid[i];
+        cbox_out[p] = cbox[i];
+        return;
+    }
+    const int j = nn[i];
+    const int idx = next_id - leader_scan[i];
+    const Box a = cbox[i], b = cbox[j];
+    Box u;
+    for (int k = 0; k < 3; ++k) { u.lo[k] = fminf(a.lo[k], b.lo[k]); u.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+    RadixNode nd;
+    nd.left = cid[i];
+    nd.right = cid[j];
+    nd.first = 0;
+    nd.last = 0;
+    nodes[idx] = nd;
+    node_boxes[idx] = u;
+    if (nd.left & kLeafBit) parent_of_leaf[nd.left & ~kLeafBit] = idx; else parent_of_internal[nd.left] = idx;
+    if (nd.right & kLeafBit) parent_of_leaf[nd.right & ~kLeafBit] = idx; else parent_of_internal[nd.right] = idx;
+    cid_out[p] = idx;
+    cbox_out[p] = u;
+}
+
+__global__ void __launch_bounds__(256) k_ploc_init(const unsigned long long* keys, const Box* prim_boxes, int n, int* cid, Box* cbox) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    cid[k] = k | kLeafBit;
+    cbox[k] = prim_boxes[(unsigned)(keys[k] & 0xffffffffu)];
+}
+
+// leaves under every node, bottom-up (the second child to arrive owns the node)
+__global__ void __launch_bounds__(256) k_ploc_count(int n, const RadixNode* nodes, const int* parent_of_internal, const int* parent_of_leaf, int* count, int* arrivals) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    int cur = parent_of_leaf[k];
+    while (cur >= 0) {
+        __threadfence();
+        const int prev = atomicAdd(&arrivals[cur], 1);
+        if (prev == 0) return;
+        __threadfence();
+        const RadixNode nd = nodes[cur];
+        const int cl = (nd.left & kLeafBit) ? 1 : __hip_atomic_load(&count[nd.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int cr = (nd.right & kLeafBit) ? 1 : __hip_atomic_load(&count[nd.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&count[cur], cl + cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur = parent_of_internal[cur];
+    }
+}
+
+// Depth-first position of every leaf (left subtree first): the leaves in front of it are those of the left siblings along
+// its path to the root.  On the way up the leaf also reports itself as the first leaf of every ancestor it reaches through
+// left edges only, and as the last of those it reaches through right edges only.
+__global__ void __launch_bounds__(256) k_ploc_order(int n, RadixNode* nodes, const int* parent_of_internal, const int* parent_of_leaf, const int* count, int* dfs_pos) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    int me = k | kLeafBit;
+    int cur = parent_of_leaf[k];
+    int pos = 0;
+    while (cur >= 0) {
+        const RadixNode nd = nodes[cur];
+        if (nd.right == me) pos += (nd.left & kLeafBit) ? 1 : count[nd.left];
+        me = cur;
+        cur = parent_of_internal[cur];
+    }
+    dfs_pos[k] = pos;
+}
+__global__ void __launch_bounds__(256) k_ploc_ranges(int n, RadixNode* nodes, const int* parent_of_internal, const int* parent_of_leaf, const int* dfs_pos) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int pos = dfs_pos[k];
+    int me = k | kLeafBit;
+    bool all_left = true, all_right = true;
+    for (int cur = parent_of_leaf[k]; cur >= 0 && (all_left || all_right); cur = parent_of_internal[cur]) {
+        const bool from_left = nodes[cur].left == me;
+        all_left = all_left && from_left;
+        all_right = all_right && !from_left;
+        if (all_left) nodes[cur].first = pos;
+        if (all_right) nodes[cur].last = pos;
+        me = cur;
+    }
+}
+// sorted keys, leaf parents and leaf references re-expressed in depth-first positions: from here on a node covers the
+// contiguous range [first, last] again and the rest of the pipeline (collapse, emit, pack) does not know the difference
+__global__ void __launch_bounds__(256) k_ploc_permute(int n, const unsigned long long* keys, const int* parent_of_leaf, const int* dfs_pos,
+                                                      unsigned long long* keys_out, int* parent_of_leaf_out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int p = dfs_pos[k];
+    keys_out[p] = keys[k];
+    parent_of_leaf_out[p] = parent_of_leaf[k];
+}
+__global__ void __launch_bounds__(256) k_ploc_relabel(int n_internal, RadixNode* nodes, const int* dfs_pos) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_internal) return;
+    RadixNode nd = nodes[i];
+    if (nd.left & kLeafBit) nd.left = dfs_pos[nd.left & ~kLeafBit] | kLeafBit;
+    if (nd.right & kLeafBit) nd.right = dfs_pos[nd.right & ~kLeafBit] | kLeafBit;
+    nodes[i] = nd;
+}
+
+// a node survives as an interior node of the output iff it covers more than kMaxLeaf triangles.  (Round 3 also tried the
+// host builder's SAH termination here -- leaf iff A N <= visit_cost A + cost(children), bottom-up: 73 % more nodes, +2 %
+// render rate, +15 ms of host work downstream for 1M triangles: not kept, profiles/r03/t_*.)
 __global__ void __launch_bounds__(256) k_flags(const RadixNode* nodes, int n_internal, int* flags) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_internal) flags[i] = (nodes[i].last - nodes[i].first + 1) > kMaxLeaf ? 1 : 0;
 }
 
-__device__ __forceinline__ int child_ref(const RadixNode* nodes, const int* out_index, int c) {
+__device__ __forceinline__ int child_ref(const RadixNode* nodes, const int* flags, const int* out_index, int c) {
     if (c & kLeafBit) return ~(((c & ~kLeafBit) << 3) | 0);
+    if (flags[c]) return out_index[c];
     const RadixNode nd = nodes[c];
-    const int len = nd.last - nd.first + 1;
-    if (len <= kMaxLeaf) return ~((nd.first << 3) | (len - 1));
-    return out_index[c];
+    return ~((nd.first << 3) | (nd.last - nd.first));
 }
 
 __global__ void __launch_bounds__(256) k_emit(const unsigned long long* keys, const RadixNode* nodes, int n_internal, const int* flags, const int* out_index,
@@ -216,8 +376,8 @@ __global__ void __launch_bounds__(256) k_emit(const unsigned long long* keys, co
             o.q[a][side * 2 + 1] = b.hi[a];
         }
     }
-    o.left = child_ref(nodes, out_index, nd.left);
-    o.right = child_ref(nodes, out_index, nd.right);
+    o.left = child_ref(nodes, flags, out_index, nd.left);
+    o.right = child_ref(nodes, flags, out_index, nd.right);
     o.pad[0] = o.pad[1] = 0;
     out[out_index[i]] = o;
 }
@@ -262,7 +422,7 @@ __global__ void __launch_bounds__(256) k_pack(const unsigned long long* keys, in
 
 // Builds the tree for n (> kMaxLeaf) triangles given in add order on the HOST; every step after the
 // upload runs on the device.  On success the caller owns out->* (hipFree).
-hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, hipStream_t stream, LbvhResult* out) {
+hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, int ploc_radius, hipStream_t stream, LbvhResult* out) {
     pt_triangle* d_tris = nullptr;
     int32_t* d_rank = nullptr;
     Box *d_pbox = nullptr, *d_nbox = nullptr;
@@ -270,12 +430,18 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, h
     RadixNode* d_rnodes = nullptr;
     int *d_pint = nullptr, *d_pleaf = nullptr, *d_arr = nullptr, *d_flags = nullptr, *d_oidx = nullptr, *d_misc = nullptr;
     void* d_temp = nullptr;
+    // PLOC (ploc_radius > 0): two cluster lists, nearest neighbours, flags + scans, leaf counts, depth-first positions
+    int *d_cidA = nullptr, *d_cidB = nullptr, *d_nn = nullptr, *d_leader = nullptr, *d_keep = nullptr, *d_lscan = nullptr, *d_kscan = nullptr;
+    int *d_count = nullptr, *d_dfs = nullptr, *d_pleaf2 = nullptr;
+    Box *d_cboxA = nullptr, *d_cboxB = nullptr;
+    unsigned long long* d_keys3 = nullptr;
     Node64* d_out = nullptr;
     TriPacket* d_packets = nullptr;
     TriMeta* d_meta = nullptr;
     int32_t* d_orig = nullptr;
     auto cleanup = [&]() {
-        void* ptrs[] = {d_tris, d_rank, d_pbox, d_nbox, d_keys, d_keys2, d_rnodes, d_pint, d_pleaf, d_arr, d_flags, d_oidx, d_misc, d_temp};
+        void* ptrs[] = {d_tris, d_rank, d_pbox, d_nbox, d_keys, d_keys2, d_rnodes, d_pint, d_pleaf, d_arr, d_flags, d_oidx, d_misc, d_temp,
+                        d_cidA, d_cidB, d_nn, d_leader, d_keep, d_lscan, d_kscan, d_count, d_dfs, d_pleaf2, d_cboxA, d_cboxB, d_keys3};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     };
     auto cleanup_all = [&]() {
@@ -287,6 +453,7 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, h
     };
     const int ni = n - 1;
     const int blocks_n = (n + 255) / 256, blocks_i = (ni + 255) / 256;
+    PhaseClock clk("device bvh");
     LB_HIP(hipMalloc((void**)&d_tris, sizeof(pt_triangle) * (size_t)n));
     LB_HIP(hipMalloc((void**)&d_rank, sizeof(int32_t) * (size_t)n));
     LB_HIP(hipMemcpyAsync(d_tris, h_tris, sizeof(pt_triangle) * (size_t)n, hipMemcpyHostToDevice, stream));
@@ -320,12 +487,68 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, h
     size_t temp_bytes = 0;
     LB_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, d_keys, d_keys2, n, 0, 64, stream));
     size_t scan_bytes = 0;
-    LB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags, d_oidx, ni, stream));
+    LB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags, d_oidx, n, stream));
     LB_HIP(hipMalloc(&d_temp, std::max(temp_bytes, scan_bytes) + 256));
     LB_HIP(hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys2, n, 0, 64, stream));
     const unsigned long long* keys = d_keys2;
-    hipLaunchKernelGGL(k_karras, dim3(blocks_i), dim3(256), 0, stream, keys, n, d_rnodes, d_pint, d_pleaf);
-    hipLaunchKernelGGL(k_fit, dim3(blocks_n), dim3(256), 0, stream, keys, n, d_pbox, d_rnodes, d_pint, d_pleaf, d_nbox, d_arr);
+    if (clk.on) { LB_HIP(hipStreamSynchronize(stream)); clk.lap("upload + boxes + morton + sort"); }
+    if (ploc_radius > 0) {
+        LB_HIP(hipMalloc((void**)&d_cidA, sizeof(int) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_cidB, sizeof(int) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_cboxA, sizeof(Box) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_cboxB, sizeof(Box) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_nn, sizeof(int) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_leader, sizeof(int) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_keep, sizeof(int) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_lscan, sizeof(int) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_kscan, sizeof(int) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_count, sizeof(int) * (size_t)ni));
+        LB_HIP(hipMalloc((void**)&d_dfs, sizeof(int) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_pleaf2, sizeof(int) * (size_t)n));
+        LB_HIP(hipMalloc((void**)&d_keys3, sizeof(unsigned long long) * (size_t)n));
+        LB_HIP(hipMemsetAsync(d_pint, 0xff, sizeof(int) * (size_t)ni, stream));        // the root keeps parent -1
+        hipLaunchKernelGGL(k_ploc_init, dim3(blocks_n), dim3(256), 0, stream, keys, d_pbox, n, d_cidA, d_cboxA);
+        int m = n, created = 0;
+        int *cid = d_cidA, *cid_out = d_cidB;
+        Box *cbox = d_cboxA, *cbox_out = d_cboxB;
+        int rounds = 0;
+        while (m > 1) {
+            const int blocks_m = (m + 255) / 256;
+            if (ploc_radius <= 8) hipLaunchKernelGGL(k_ploc_nn<8>, dim3(blocks_m), dim3(256), 0, stream, cbox, m, d_nn);
+            else if (ploc_radius <= 16) hipLaunchKernelGGL(k_ploc_nn<16>, dim3(blocks_m), dim3(256), 0, stream, cbox, m, d_nn);
+            else hipLaunchKernelGGL(k_ploc_nn<32>, dim3(blocks_m), dim3(256), 0, stream, cbox, m, d_nn);
+            hipLaunchKernelGGL(k_ploc_mark, dim3(blocks_m), dim3(256), 0, stream, d_nn, m, d_leader, d_keep);
+            LB_HIP(hipGetLastError());
+            LB_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp, scan_bytes, d_leader, d_lscan, m, stream));
+            LB_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp, scan_bytes, d_keep, d_kscan, m, stream));
+            int last_leader = 0, last_scan = 0;
+            LB_HIP(hipMemcpyAsync(&last_leader, d_leader + (m - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            LB_HIP(hipMemcpyAsync(&last_scan, d_lscan + (m - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            LB_HIP(hipStreamSynchronize(stream));
+            const int merges = last_leader + last_scan;
+            if (merges < 1 || ++rounds > 4096) { cleanup_all(); return hipErrorUnknown; }      // (cannot happen: the smallest pair is always mutual)
+            hipLaunchKernelGGL(k_ploc_apply, dim3(blocks_m), dim3(256), 0, stream, cid, cbox, d_nn, d_leader, d_lscan, d_keep, d_kscan, m, (ni - 1) - created,
+                               d_rnodes, d_nbox, d_pint, d_pleaf, cid_out, cbox_out);
+            LB_HIP(hipGetLastError());
+            created += merges;
+            m -= merges;
+            std::swap(cid, cid_out);
+            std::swap(cbox, cbox_out);
+        }
+        if (created != ni) { cleanup_all(); return hipErrorUnknown; }
+        if (clk.on) { std::fprintf(stderr, "[device bvh] PLOC rounds %d\n", rounds); clk.lap("PLOC merges"); }
+        hipLaunchKernelGGL(k_ploc_count, dim3(blocks_n), dim3(256), 0, stream, n, d_rnodes, d_pint, d_pleaf, d_count, d_arr);
+        hipLaunchKernelGGL(k_ploc_order, dim3(blocks_n), dim3(256), 0, stream, n, d_rnodes, d_pint, d_pleaf, d_count, d_dfs);
+        hipLaunchKernelGGL(k_ploc_ranges, dim3(blocks_n), dim3(256), 0, stream, n, d_rnodes, d_pint, d_pleaf, d_dfs);
+        hipLaunchKernelGGL(k_ploc_permute, dim3(blocks_n), dim3(256), 0, stream, n, keys, d_pleaf, d_dfs, d_keys3, d_pleaf2);
+        hipLaunchKernelGGL(k_ploc_relabel, dim3(blocks_i), dim3(256), 0, stream, ni, d_rnodes, d_dfs);
+        LB_HIP(hipGetLastError());
+        keys = d_keys3;
+        std::swap(d_pleaf, d_pleaf2);
+    } else {
+        hipLaunchKernelGGL(k_karras, dim3(blocks_i), dim3(256), 0, stream, keys, n, d_rnodes, d_pint, d_pleaf);
+        hipLaunchKernelGGL(k_fit, dim3(blocks_n), dim3(256), 0, stream, keys, n, d_pbox, d_rnodes, d_pint, d_pleaf, d_nbox, d_arr);
+    }
     hipLaunchKernelGGL(k_flags, dim3(blocks_i), dim3(256), 0, stream, d_rnodes, ni, d_flags);
     LB_HIP(hipGetLastError());
     LB_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp, scan_bytes, d_flags, d_oidx, ni, stream));
@@ -345,7 +568,9 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, h
     hipLaunchKernelGGL(k_pack, dim3(blocks_n), dim3(256), 0, stream, keys, n, d_tris, d_rank, d_packets, d_meta, d_orig);
     LB_HIP(hipGetLastError());
     LB_HIP(hipStreamSynchronize(stream));
+    clk.lap("order + collapse + emit + pack");
     cleanup();
+    clk.lap("free");
     out->d_nodes = reinterpret_cast<float4*>(d_out);
     out->n_nodes = n_out;
     out->d_tris = reinterpret_cast<float4*>(d_packets);

@@ -701,9 +701,9 @@ def test_closest_hit_adversarial_rays(api, oracle, cb_spec, cb_oracle_scene, lds
 
 @pytest.mark.parametrize("which,ntris", [("cornell", 0), ("mesh", 6000), ("mesh", 100000)])
 def test_device_bvh_builder(api, oracle, cb_spec, cb_oracle_scene, which, ntris):
-    """bvh_policy 4: the tree is built ON THE DEVICE (LBVH: Morton codes, radix sort, Karras,
-    pt_lbvh.hip -- SURVEY 8f row 3).  The closest hit does not depend on the tree, so the render
-    must be bit-identical to the oracle just like with the host SAH builder; the emitted tree must
+    """bvh_policy 4: the tree is built ON THE DEVICE (Morton codes, radix sort, then PLOC merges -- or Karras'
+    radix tree with lbvh_ploc 0 -- pt_lbvh.hip).  The closest hit does not depend on the tree, so
+    the render must be bit-identical to the oracle just like with the host SAH builder; the emitted tree must
     be a valid BVH over all triangles."""
     import bvh_check
     from opencl_path_tracer_amd import scenes
@@ -713,15 +713,23 @@ def test_device_bvh_builder(api, oracle, cb_spec, cb_oracle_scene, which, ntris)
         spec = scenes.displaced_grid_mesh(ntris)
         osc = oracle.load_scene(spec)
     W, H = 64, 48
-    sc = api.Scene(W, H)
-    sc.set_option("bvh_policy", 4)
-    sc.load(spec)
-    assert sc.stat("bvh_on_device") == 1
-    nodes, tris, meta, orig = sc.debug_bvh()
-    assert sorted(orig.tolist()) == list(range(spec.ntris))
-    if spec.ntris < 10000:
-        depth = bvh_check.validate_structure(nodes, tris, spec.ntris, int(sc.stat("flat_triangles")))
-        assert depth <= sc.stat("bvh_depth")
+    for ploc, cluster in ((0, 64), (8, 0), (32, 8), (16, 64)):        # radix tree; PLOC at each radius, with / without the SAH top; last = the default
+        sc = api.Scene(W, H)
+        sc.set_option("bvh_policy", 4)
+        sc.set_option("lbvh_ploc", ploc)
+        sc.set_option("lbvh_cluster", cluster)
+        sc.load(spec)
+        assert sc.stat("bvh_on_device") == 1
+        nodes, tris, meta, orig = sc.debug_bvh()
+        assert sorted(orig.tolist()) == list(range(spec.ntris))
+        if spec.ntris < 10000:
+            depth = bvh_check.validate_structure(nodes, tris, spec.ntris, int(sc.stat("flat_triangles")))
+            assert depth <= sc.stat("bvh_depth")
+        if (ploc, cluster) != (16, 64):
+            sc.iterations = 6
+            sc.render(1)
+            fr1, _ = oracle_render(oracle, osc, spec, W, H, 6, 1)
+            check(sc, fr1, "device bvh %s ploc %d cluster %d" % (which, ploc, cluster))
     sc.iterations = 6
     sc.render(2)
     fr, segs = oracle_render(oracle, osc, spec, W, H, 6, 2)

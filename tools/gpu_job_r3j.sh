@@ -19,4 +19,7 @@ tools/pmc_passes.sh r3j_wf scene=cornell spp=4 reps=2 variant=1 > gpurun_out/r3j
 tail -22 gpurun_out/r3j_pmc_wf_record.log
 timeout -k 10 300 python3 tools/tile_cost_histogram.py > gpurun_out/r3j_tile_cost.txt 2>&1; cat gpurun_out/r3j_tile_cost.txt
 PTAMD_TRACE=1 timeout -k 10 300 python3 tools/obj_load_time.py 1000000 > gpurun_out/r3j_obj_load.txt 2>&1; tail -14 gpurun_out/r3j_obj_load.txt
-echo done
+echo done1
+timeout -k 10 600 python3 tools/scaling_probe2.py 3840 2160 > gpurun_out/r3j_probe_4k.txt 2>&1; cat gpurun_out/r3j_probe_4k.txt
+timeout -k 10 300 python3 tools/one_spp.py > gpurun_out/r3j_one_spp.txt 2>&1; cat gpurun_out/r3j_one_spp.txt
+echo done2
