@@ -2,13 +2,14 @@
 // on the host, NodeOnHost::build/convert, main.cpp:195-304, which is what makes scene upload slow
 // for large meshes and rules out per-frame rebuilds).
 //
-// Linear BVH: 30-bit Morton codes of the triangle centroids (made unique with the triangle index in
-// the low word), one 64-bit radix sort (hipCUB), Karras' parallel radix-tree construction, bottom-up
-// box fitting with one arrival counter per node, then a collapse of every subtree of <= 4 triangles
-// into a leaf and emission in the SAME 64-byte node / 48-byte packet layout the host builder
-// produces (pt_internal.hpp) -- the traversal kernels do not know which builder made the tree.
-// The closest hit does not depend on the tree, so renders are bit-identical
-// with either builder; only the traversal cost differs (an LBVH is looser than the SAH tree).
+// 30-bit Morton codes of the triangle centroids (made unique with the triangle index in the low word), one 64-bit radix
+// sort (hipCUB), then the hierarchy: PLOC merges over the Morton order (default; k_ploc_*: nearest neighbour by box area
+// within a window, mutual pairs merge, survivors are compacted, repeat) or Karras' parallel radix tree (option lbvh_ploc 0)
+// with bottom-up box fitting; then a collapse of every subtree of <= 4 triangles into a leaf and emission in the SAME
+// 64-byte node / 48-byte packet layout the host builder produces (pt_internal.hpp) -- the traversal kernels do not know
+// which builder made the tree.  The closest hit does not depend on the tree, so renders are
+// bit-identical with either builder; only the traversal cost differs (PLOC: 0.64-0.83x of the SAH tree's render rate,
+// the Morton radix tree 0.43-0.69x: profiles/r03/t_*).
 #include "pt_internal.hpp"
 
 #include <hipcub/hipcub.hpp>
