@@ -71,6 +71,7 @@ struct pt_context {
     std::vector<Node4q> nodes4;   // the same tree collapsed to 4-wide quantised nodes (empty: not built), pt_wide.cpp
     int wide_pending = 0;         // most entries a wide traversal can have pushed when it visits an interior node
     std::vector<TriPacket> packets;
+    bool host_packets_stale = false;   // device-built tree: packets / meta behind the big-triangle list live on the device only until a debug getter asks
     std::vector<TriMeta> meta;
     std::vector<int32_t> orig;
     int bvh_depth = 0;
@@ -1520,6 +1521,7 @@ int pt_end_obj(pt_context* ctx) {
 static bool sah_top_rebuild(pt_context* ctx, int cluster) {
     std::vector<Node64>& old = ctx->nodes;
     if (cluster <= 0 || old.size() < 64) return false;
+    PhaseClock clk("sah top");
     // triangles below every node (post-order over an explicit stack; children are visited before their parent is closed)
     std::vector<int32_t> count(old.size(), 0);
     {
@@ -1541,6 +1543,7 @@ static bool sah_top_rebuild(pt_context* ctx, int cluster) {
             }
         }
     }
+    clk.lap("triangle counts");
     if (count[0] <= cluster * 4) return false;
     // the cut: children that are leaves or small enough become clusters
     struct Cluster { int32_t ref; Aabb box; };
@@ -1562,6 +1565,7 @@ static bool sah_top_rebuild(pt_context* ctx, int cluster) {
             }
         }
     }
+    clk.lap("cut");
     if (clusters.size() < 4) return false;
     BvhBuilder top;
     top.prims.resize(clusters.size());
@@ -1576,6 +1580,7 @@ static bool sah_top_rebuild(pt_context* ctx, int cluster) {
     top.visit_cost = (float)ctx->sah_visit_cost * 0.1f;
     Aabb box;
     if (top.build(0, top.prims.size(), 0, &box) != 0) return false;
+    clk.lap("SAH over the clusters");
     // splice: top nodes in preorder, every cluster's subtree copied right where the top tree refers to it
     std::vector<Node64> out;
     out.reserve(old.size() + top.nodes.size());
@@ -1612,7 +1617,9 @@ static bool sah_top_rebuild(pt_context* ctx, int cluster) {
         }
     } emit{top, clusters, copy, out};
     emit.node(0);
+    clk.lap("splice");
     if (deepest_interior_node(out) + 2 > kStackEntries) return false;
+    clk.lap("depth check");
     old.swap(out);
     return true;
 }
@@ -1645,71 +1652,50 @@ static int build_on_device(pt_context* ctx, bool* done) {
     const std::vector<int32_t> flat = select_flat_list(ctx, prims);
     const int nf = (int)flat.size(), ns = n - nf;
     if (ns <= 2 * kMaxLeaf) return PT_OK;
-    std::vector<pt_triangle> sub_tris;
-    std::vector<int32_t> sub_rank, sub_orig;
-    const pt_triangle* b_tris = ctx->tris.data();
-    const int32_t* b_rank = ctx->enc_rank.data();
+    // what goes into the tree: an index list (the device gathers; the triangles are uploaded once, as they are)
+    std::vector<int32_t> sel;
     if (nf > 0) {
-        sub_tris.resize((size_t)ns);
-        sub_rank.resize((size_t)ns);
-        sub_orig.resize((size_t)ns);
-        parallel_for((size_t)ns, 1 << 14, threads, [&](size_t b, size_t e) {
-            for (size_t k = b; k < e; ++k) {
-                const int32_t t = prims[k].tri;
-                sub_tris[k] = ctx->tris[(size_t)t];
-                sub_rank[k] = ctx->enc_rank[(size_t)t];
-                sub_orig[k] = t;
-            }
-        });
-        b_tris = sub_tris.data();
-        b_rank = sub_rank.data();
+        sel.resize((size_t)ns);
+        parallel_for((size_t)ns, 1 << 15, threads, [&](size_t b, size_t e) { for (size_t k = b; k < e; ++k) sel[k] = prims[k].tri; });
     }
-    clk.lap("boxes + big-triangle list + gather");
+    std::vector<BuildPrim>().swap(prims);
+    clk.lap("boxes + big-triangle list");
     LbvhResult r;
-    PT_HIP(ctx, lbvh_build(b_tris, b_rank, ns, ctx->lbvh_ploc, ctx->stream, &r));
+    PT_HIP(ctx, lbvh_build(ctx->tris.data(), ctx->enc_rank.data(), n, nf > 0 ? sel.data() : nullptr, ns, ctx->lbvh_ploc, ctx->stream, &r));
     clk.lap("lbvh_build");
     auto drop = [&]() { (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta); (void)hipFree(r.d_orig); };
     if (r.depth + 5 > kStackEntries) {          // deeper than the traversal stack: let the host builder do it
         drop();
         return PT_OK;
     }
+    // The device arrays are final but for the list's nf slots in front, which are written here (leaf references already count
+    // from behind them).  The host keeps the nodes (SAH top, 4-wide collapse, debug getters) and the order; packets and meta
+    // of the tree's triangles stay on the device until a debug getter asks for them (host_packets_stale).
     ctx->nodes.resize((size_t)r.n_nodes);
-    ctx->packets.resize((size_t)n);
-    ctx->meta.resize((size_t)n);
     ctx->orig.resize((size_t)n);
+    ctx->packets.assign((size_t)std::max(nf, 1), TriPacket());
+    ctx->meta.assign((size_t)std::max(nf, 1), TriMeta());
     hipError_t e = hipMemcpy(ctx->nodes.data(), r.d_nodes, sizeof(Node64) * (size_t)r.n_nodes, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(ctx->packets.data() + nf, r.d_tris, sizeof(TriPacket) * (size_t)ns, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(ctx->meta.data() + nf, r.d_meta, sizeof(TriMeta) * (size_t)ns, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(ctx->orig.data() + nf, r.d_orig, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ctx->orig.data() + nf, reinterpret_cast<int32_t*>(r.d_orig) + nf, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost);
+    for (int k = 0; k < nf; ++k) {
+        const pt_triangle& t = ctx->tris[(size_t)flat[(size_t)k]];
+        float* v = ctx->packets[(size_t)k].v;
+        v[0] = t.r1.s[0]; v[1] = t.r1.s[1]; v[2] = t.r1.s[2];
+        v[3] = t.r2.s[0]; v[4] = t.r2.s[1]; v[5] = t.r2.s[2];
+        v[6] = t.r3.s[0]; v[7] = t.r3.s[1]; v[8] = t.r3.s[2];
+        v[9] = t.N.s[0]; v[10] = t.N.s[1]; v[11] = t.N.s[2];
+        ctx->meta[(size_t)k].rank = ctx->enc_rank[(size_t)flat[(size_t)k]];
+        ctx->meta[(size_t)k].mati = t.mati;
+        ctx->orig[(size_t)k] = flat[(size_t)k];
+    }
+    if (e == hipSuccess && nf > 0) e = hipMemcpy(r.d_tris, ctx->packets.data(), sizeof(TriPacket) * (size_t)nf, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nf > 0) e = hipMemcpy(r.d_meta, ctx->meta.data(), sizeof(TriMeta) * (size_t)nf, hipMemcpyHostToDevice);
     if (e != hipSuccess) { drop(); return fail(ctx, PT_EHIP, std::string("device BVH download: ") + hipGetErrorString(e)); }
     (void)hipFree(r.d_orig);
     r.d_orig = nullptr;
+    ctx->host_packets_stale = true;
     ctx->bvh_depth = r.depth + 1;
     ctx->n_flat = nf;
-    if (nf > 0) {
-        // the list's packets go in front; leaf ranges move up by nf (a leaf reference is ~(first << 3 | count - 1))
-        for (int k = 0; k < nf; ++k) {
-            const pt_triangle& t = ctx->tris[(size_t)flat[(size_t)k]];
-            float* v = ctx->packets[(size_t)k].v;
-            v[0] = t.r1.s[0]; v[1] = t.r1.s[1]; v[2] = t.r1.s[2];
-            v[3] = t.r2.s[0]; v[4] = t.r2.s[1]; v[5] = t.r2.s[2];
-            v[6] = t.r3.s[0]; v[7] = t.r3.s[1]; v[8] = t.r3.s[2];
-            v[9] = t.N.s[0]; v[10] = t.N.s[1]; v[11] = t.N.s[2];
-            ctx->meta[(size_t)k].rank = ctx->enc_rank[(size_t)flat[(size_t)k]];
-            ctx->meta[(size_t)k].mati = t.mati;
-            ctx->orig[(size_t)k] = flat[(size_t)k];
-        }
-        parallel_for((size_t)(n - nf), 1 << 15, threads, [&](size_t b, size_t e) {
-            for (size_t k = (size_t)nf + b; k < (size_t)nf + e; ++k) ctx->orig[k] = sub_orig[(size_t)ctx->orig[k]];
-        });
-        parallel_for(ctx->nodes.size(), 1 << 15, threads, [&](size_t b, size_t e) {
-            for (size_t i = b; i < e; ++i) {
-                Node64& nd = ctx->nodes[i];
-                if (nd.left < 0) nd.left -= nf << 3;
-                if (nd.right < 0) nd.right -= nf << 3;
-            }
-        });
-    }
     clk.lap("download + list in front");
     const bool retopped = sah_top_rebuild(ctx, ctx->lbvh_cluster);
     clk.lap("SAH top over clusters");
@@ -1717,18 +1703,16 @@ static int build_on_device(pt_context* ctx, bool* done) {
     clk.lap("node placement + 4-wide nodes");
     if (rc != PT_OK) { drop(); return rc; }
     if (retopped) ctx->bvh_depth = ctx->interior_depth + 1;
-    if (nf > 0 || retopped) {     // recomposed on the host: replace the builder's device arrays
-        (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta);
+    if (ctx->d_tris) (void)hipFree(ctx->d_tris);
+    if (ctx->d_meta) (void)hipFree(ctx->d_meta);
+    ctx->d_tris = r.d_tris;
+    ctx->d_meta = r.d_meta;
+    if (retopped) {               // the nodes were recomposed on the host
+        (void)hipFree(r.d_nodes);
         if ((rc = upload_vec(ctx, &ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size())) != PT_OK) return rc;
-        if ((rc = upload_vec(ctx, &ctx->d_tris, ctx->packets.data(), sizeof(TriPacket) * ctx->packets.size())) != PT_OK) return rc;
-        if ((rc = upload_vec(ctx, &ctx->d_meta, ctx->meta.data(), sizeof(TriMeta) * ctx->meta.size())) != PT_OK) return rc;
     } else {
         if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
-        if (ctx->d_tris) (void)hipFree(ctx->d_tris);
-        if (ctx->d_meta) (void)hipFree(ctx->d_meta);
         ctx->d_nodes = r.d_nodes;
-        ctx->d_tris = r.d_tris;
-        ctx->d_meta = r.d_meta;
         if (ctx->treelet_nodes > 0) PT_HIP(ctx, hipMemcpy(ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size(), hipMemcpyHostToDevice));
     }
     if ((rc = upload_vec(ctx, &ctx->d_nodes4, ctx->nodes4.data(), sizeof(Node4q) * ctx->nodes4.size())) != PT_OK) return rc;
@@ -1758,6 +1742,7 @@ int pt_upload_triangles(pt_context* ctx) {
         }
     }
     ctx->bvh_on_device = 0;
+    ctx->host_packets_stale = false;
     int rc = build_and_pack(ctx);
     if (rc != PT_OK) return rc;
     PhaseClock clk("pt_upload_triangles");
@@ -2311,8 +2296,18 @@ int pt_debug_wide_nodes(const pt_context* ctx, void* out, int64_t capacity, int6
     return PT_OK;
 }
 
-int pt_debug_bvh_copy(const pt_context* ctx, float* nodes, float* tris, int32_t* meta, int32_t* orig) {
-    if (!ctx || !ctx->tris_uploaded) return PT_EINVAL;
+int pt_debug_bvh_copy(const pt_context* cctx, float* nodes, float* tris, int32_t* meta, int32_t* orig) {
+    if (!cctx || !cctx->tris_uploaded) return PT_EINVAL;
+    pt_context* ctx = const_cast<pt_context*>(cctx);            // (the host mirror of a device-built tree is filled on demand)
+    if (ctx->host_packets_stale && (tris || meta)) {
+        const size_t m = ctx->orig.size();
+        ctx->packets.resize(m);
+        ctx->meta.resize(m);
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        PT_HIP(ctx, hipMemcpy(ctx->packets.data(), ctx->d_tris, sizeof(TriPacket) * m, hipMemcpyDeviceToHost));
+        PT_HIP(ctx, hipMemcpy(ctx->meta.data(), ctx->d_meta, sizeof(TriMeta) * m, hipMemcpyDeviceToHost));
+        ctx->host_packets_stale = false;
+    }
     if (nodes) std::memcpy(nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size());
     if (tris) std::memcpy(tris, ctx->packets.data(), sizeof(TriPacket) * ctx->orig.size());
     if (meta) std::memcpy(meta, ctx->meta.data(), sizeof(TriMeta) * ctx->orig.size());

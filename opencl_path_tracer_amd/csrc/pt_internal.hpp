@@ -173,7 +173,7 @@ struct LbvhResult {
     int32_t* d_orig = nullptr;
     int depth = 0;
 };
-hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, int ploc_radius, hipStream_t stream, LbvhResult* out);
+hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_all, const int32_t* h_sel, int n, int ploc_radius, hipStream_t stream, LbvhResult* out);
 
 struct LaunchConfig {
     int block = 256;                   // traversal_block(node_mode)

@@ -57,12 +57,13 @@ __device__ __forceinline__ Box tri_bounds(const pt_triangle& t, bool* finite) {
     return b;
 }
 
-__global__ void __launch_bounds__(256) k_prim_bounds(const pt_triangle* tris, int n, Box* boxes, int* cbounds /*[6] ordered ints*/) {
+// (sel: the add-order indices of the triangles that go into the tree -- all but the big-triangle list -- or null for all)
+__global__ void __launch_bounds__(256) k_prim_bounds(const pt_triangle* tris, const int32_t* sel, int n, Box* boxes, int* cbounds /*[6] ordered ints*/) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     float c[3] = {0.f, 0.f, 0.f};
     bool ok = false;
     if (i < n) {
-        Box b = tri_bounds(tris[i], &ok);
+        Box b = tri_bounds(tris[sel ? sel[i] : i], &ok);
         if (!ok) {                       // cannot be hit (prog.cl:99-106 compares NaN): empty box
             for (int a = 0; a < 3; ++a) { b.lo[a] = __builtin_inff(); b.hi[a] = -__builtin_inff(); }
         }
@@ -356,15 +357,16 @@ __global__ void __launch_bounds__(256) k_flags(const RadixNode* nodes, int n_int
     if (i < n_internal) flags[i] = (nodes[i].last - nodes[i].first + 1) > kMaxLeaf ? 1 : 0;
 }
 
-__device__ __forceinline__ int child_ref(const RadixNode* nodes, const int* flags, const int* out_index, int c) {
-    if (c & kLeafBit) return ~(((c & ~kLeafBit) << 3) | 0);
+// (leaf_base: packets in front of the tree's -- the big-triangle list; a leaf reference is ~(first packet << 3 | count - 1))
+__device__ __forceinline__ int child_ref(const RadixNode* nodes, const int* flags, const int* out_index, int c, int leaf_base) {
+    if (c & kLeafBit) return ~((((c & ~kLeafBit) + leaf_base) << 3) | 0);
     if (flags[c]) return out_index[c];
     const RadixNode nd = nodes[c];
-    return ~((nd.first << 3) | (nd.last - nd.first));
+    return ~(((nd.first + leaf_base) << 3) | (nd.last - nd.first));
 }
 
 __global__ void __launch_bounds__(256) k_emit(const unsigned long long* keys, const RadixNode* nodes, int n_internal, const int* flags, const int* out_index,
-                                              const Box* prim_boxes, const Box* node_boxes, Node64* out) {
+                                              const Box* prim_boxes, const Box* node_boxes, int leaf_base, Node64* out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_internal || !flags[i]) return;
     const RadixNode nd = nodes[i];
@@ -377,8 +379,8 @@ __global__ void __launch_bounds__(256) k_emit(const unsigned long long* keys, co
             o.q[a][side * 2 + 1] = b.hi[a];
         }
     }
-    o.left = child_ref(nodes, flags, out_index, nd.left);
-    o.right = child_ref(nodes, flags, out_index, nd.right);
+    o.left = child_ref(nodes, flags, out_index, nd.left, leaf_base);
+    o.right = child_ref(nodes, flags, out_index, nd.right, leaf_base);
     o.pad[0] = o.pad[1] = 0;
     out[out_index[i]] = o;
 }
@@ -394,11 +396,12 @@ __global__ void __launch_bounds__(256) k_depth(int n, const int* flags, const in
     if ((threadIdx.x & 63) == 0) atomicMax(max_depth, d);
 }
 
-__global__ void __launch_bounds__(256) k_pack(const unsigned long long* keys, int n, const pt_triangle* tris, const int32_t* rank,
+__global__ void __launch_bounds__(256) k_pack(const unsigned long long* keys, int n, const pt_triangle* tris, const int32_t* rank, const int32_t* sel,
                                               TriPacket* packets, TriMeta* meta, int32_t* orig) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
-    const int i = (int)(unsigned)(keys[k] & 0xffffffffu);
+    const int j = (int)(unsigned)(keys[k] & 0xffffffffu);
+    const int i = sel ? sel[j] : j;                  // add-order index
     const pt_triangle t = tris[i];
     TriPacket p;
     p.v[0] = t.r1.s[0]; p.v[1] = t.r1.s[1]; p.v[2] = t.r1.s[2];
@@ -423,9 +426,14 @@ __global__ void __launch_bounds__(256) k_pack(const unsigned long long* keys, in
 
 // Builds the tree for n (> kMaxLeaf) triangles given in add order on the HOST; every step after the
 // upload runs on the device.  On success the caller owns out->* (hipFree).
-hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, int ploc_radius, hipStream_t stream, LbvhResult* out) {
+// h_tris / h_rank: ALL n_all triangles in add order; h_sel: the n of them that go into the tree (null: all, n == n_all).  The
+// packets / meta / orig arrays are emitted for n_all triangles with the tree's behind the first n_all - n slots, which the
+// caller fills (the big-triangle list); leaf references count from there.
+hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_all, const int32_t* h_sel, int n, int ploc_radius, hipStream_t stream, LbvhResult* out) {
     pt_triangle* d_tris = nullptr;
     int32_t* d_rank = nullptr;
+    int32_t* d_sel = nullptr;
+    const int nf = n_all - n;
     Box *d_pbox = nullptr, *d_nbox = nullptr;
     unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
     RadixNode* d_rnodes = nullptr;
@@ -441,7 +449,7 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, i
     TriMeta* d_meta = nullptr;
     int32_t* d_orig = nullptr;
     auto cleanup = [&]() {
-        void* ptrs[] = {d_tris, d_rank, d_pbox, d_nbox, d_keys, d_keys2, d_rnodes, d_pint, d_pleaf, d_arr, d_flags, d_oidx, d_misc, d_temp,
+        void* ptrs[] = {d_tris, d_rank, d_sel, d_pbox, d_nbox, d_keys, d_keys2, d_rnodes, d_pint, d_pleaf, d_arr, d_flags, d_oidx, d_misc, d_temp,
                         d_cidA, d_cidB, d_nn, d_leader, d_keep, d_lscan, d_kscan, d_count, d_dfs, d_pleaf2, d_cboxA, d_cboxB, d_keys3};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     };
@@ -455,10 +463,14 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, i
     const int ni = n - 1;
     const int blocks_n = (n + 255) / 256, blocks_i = (ni + 255) / 256;
     PhaseClock clk("device bvh");
-    LB_HIP(hipMalloc((void**)&d_tris, sizeof(pt_triangle) * (size_t)n));
-    LB_HIP(hipMalloc((void**)&d_rank, sizeof(int32_t) * (size_t)n));
-    LB_HIP(hipMemcpyAsync(d_tris, h_tris, sizeof(pt_triangle) * (size_t)n, hipMemcpyHostToDevice, stream));
-    LB_HIP(hipMemcpyAsync(d_rank, h_rank, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream));
+    LB_HIP(hipMalloc((void**)&d_tris, sizeof(pt_triangle) * (size_t)n_all));
+    LB_HIP(hipMalloc((void**)&d_rank, sizeof(int32_t) * (size_t)n_all));
+    LB_HIP(hipMemcpyAsync(d_tris, h_tris, sizeof(pt_triangle) * (size_t)n_all, hipMemcpyHostToDevice, stream));
+    LB_HIP(hipMemcpyAsync(d_rank, h_rank, sizeof(int32_t) * (size_t)n_all, hipMemcpyHostToDevice, stream));
+    if (h_sel) {
+        LB_HIP(hipMalloc((void**)&d_sel, sizeof(int32_t) * (size_t)n));
+        LB_HIP(hipMemcpyAsync(d_sel, h_sel, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream));
+    }
     LB_HIP(hipMalloc((void**)&d_pbox, sizeof(Box) * (size_t)n));
     LB_HIP(hipMalloc((void**)&d_nbox, sizeof(Box) * (size_t)ni));
     LB_HIP(hipMalloc((void**)&d_keys, sizeof(unsigned long long) * (size_t)n));
@@ -482,7 +494,7 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, i
         LB_HIP(hipMemcpyAsync(d_misc, init, sizeof init, hipMemcpyHostToDevice, stream));
     }
     LB_HIP(hipMemsetAsync(d_arr, 0, sizeof(int) * (size_t)ni, stream));
-    hipLaunchKernelGGL(k_prim_bounds, dim3(blocks_n), dim3(256), 0, stream, d_tris, n, d_pbox, d_misc);
+    hipLaunchKernelGGL(k_prim_bounds, dim3(blocks_n), dim3(256), 0, stream, d_tris, d_sel, n, d_pbox, d_misc);
     hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(256), 0, stream, d_pbox, n, d_misc, d_keys);
     LB_HIP(hipGetLastError());
     size_t temp_bytes = 0;
@@ -562,11 +574,11 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n, i
     const int n_out = last_idx + last_flag;
     if (n_out < 1) { cleanup_all(); return hipErrorUnknown; }
     LB_HIP(hipMalloc((void**)&d_out, sizeof(Node64) * (size_t)n_out));
-    LB_HIP(hipMalloc((void**)&d_packets, sizeof(TriPacket) * (size_t)n));
-    LB_HIP(hipMalloc((void**)&d_meta, sizeof(TriMeta) * (size_t)n));
-    LB_HIP(hipMalloc((void**)&d_orig, sizeof(int32_t) * (size_t)n));
-    hipLaunchKernelGGL(k_emit, dim3(blocks_i), dim3(256), 0, stream, keys, d_rnodes, ni, d_flags, d_oidx, d_pbox, d_nbox, d_out);
-    hipLaunchKernelGGL(k_pack, dim3(blocks_n), dim3(256), 0, stream, keys, n, d_tris, d_rank, d_packets, d_meta, d_orig);
+    LB_HIP(hipMalloc((void**)&d_packets, sizeof(TriPacket) * (size_t)n_all));
+    LB_HIP(hipMalloc((void**)&d_meta, sizeof(TriMeta) * (size_t)n_all));
+    LB_HIP(hipMalloc((void**)&d_orig, sizeof(int32_t) * (size_t)n_all));
+    hipLaunchKernelGGL(k_emit, dim3(blocks_i), dim3(256), 0, stream, keys, d_rnodes, ni, d_flags, d_oidx, d_pbox, d_nbox, nf, d_out);
+    hipLaunchKernelGGL(k_pack, dim3(blocks_n), dim3(256), 0, stream, keys, n, d_tris, d_rank, d_sel, d_packets + nf, d_meta + nf, d_orig + nf);
     LB_HIP(hipGetLastError());
     LB_HIP(hipStreamSynchronize(stream));
     clk.lap("order + collapse + emit + pack");
