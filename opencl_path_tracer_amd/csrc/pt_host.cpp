@@ -135,7 +135,8 @@ struct pt_context {
     int waves_per_simd = -1; // nodes from global memory: register budget for 4 / 5 / 6 / 7 waves per SIMD (-1: the most the LDS stacks allow)
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
-    int bvh_policy = 0;   // 0/1 host SAH with SAH leaf termination, 2 leaves of <= 4, 3 leaves of <= 8, 4 device LBVH
+    int bvh_policy = 0;   // 0/1 host SAH with SAH leaf termination, 2 leaves of <= 4, 3 leaves of <= 8, 4 device LBVH, 5 the SAH tree built on the device
+    int sah_grain = 512;  // device SAH builder: ranges of at most this many triangles are finished by one wave each
 
     // ---- statistics
     std::vector<EventPair> events;
@@ -1661,10 +1662,19 @@ static int build_on_device(pt_context* ctx, bool* done) {
     std::vector<BuildPrim>().swap(prims);
     clk.lap("boxes + big-triangle list");
     LbvhResult r;
-    PT_HIP(ctx, lbvh_build(ctx->tris.data(), ctx->enc_rank.data(), n, nf > 0 ? sel.data() : nullptr, ns, ctx->lbvh_ploc, ctx->stream, &r));
-    clk.lap("lbvh_build");
+    const bool sah = ctx->bvh_policy == 5;
+    if (sah) {                                  // the host builder's tree (policy 0), node for node; the host builds what the device cannot
+        bool unsupported = false;
+        PT_HIP(ctx, sah_device_build(ctx->tris.data(), ctx->enc_rank.data(), n, nf > 0 ? sel.data() : nullptr, ns, 4, false, (float)ctx->sah_visit_cost * 0.1f, ctx->sah_grain,
+                                     ctx->stream, &r, &unsupported));
+        if (unsupported) return PT_OK;
+        clk.lap("sah_device_build");
+    } else {
+        PT_HIP(ctx, lbvh_build(ctx->tris.data(), ctx->enc_rank.data(), n, nf > 0 ? sel.data() : nullptr, ns, ctx->lbvh_ploc, ctx->stream, &r));
+        clk.lap("lbvh_build");
+    }
     auto drop = [&]() { (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta); (void)hipFree(r.d_orig); };
-    if (r.depth + 5 > kStackEntries) {          // deeper than the traversal stack: let the host builder do it
+    if (!sah && r.depth + 5 > kStackEntries) {  // deeper than the traversal stack: let the host builder do it
         drop();
         return PT_OK;
     }
@@ -1691,13 +1701,35 @@ static int build_on_device(pt_context* ctx, bool* done) {
     if (e == hipSuccess && nf > 0) e = hipMemcpy(r.d_tris, ctx->packets.data(), sizeof(TriPacket) * (size_t)nf, hipMemcpyHostToDevice);
     if (e == hipSuccess && nf > 0) e = hipMemcpy(r.d_meta, ctx->meta.data(), sizeof(TriMeta) * (size_t)nf, hipMemcpyHostToDevice);
     if (e != hipSuccess) { drop(); return fail(ctx, PT_EHIP, std::string("device BVH download: ") + hipGetErrorString(e)); }
+    if (sah) {
+        // The SAH tree arrives in preorder: a child's index is larger than its parent's and every leaf lies inside the packed
+        // triangles behind the list.  Checked before any host code walks the tree (a malformed tree must fail here, loudly,
+        // not loop there).
+        std::atomic<bool> ok(true);
+        const int32_t nn = (int32_t)r.n_nodes;
+        parallel_for((size_t)nn, 1 << 15, threads, [&](size_t b, size_t e2) {
+            bool good = true;
+            for (size_t i = b; i < e2 && good; ++i) {
+                const int32_t refs[2] = {ctx->nodes[i].left, ctx->nodes[i].right};
+                for (int32_t ref : refs) {
+                    if (ref >= 0) good = good && ref > (int32_t)i && ref < nn;
+                    else {
+                        const int32_t first = (~ref) >> 3, count = ((~ref) & 7) + 1;
+                        good = good && first >= nf && first + count <= n;
+                    }
+                }
+            }
+            if (!good) ok.store(false);
+        });
+        if (!ok.load()) { drop(); return fail(ctx, PT_EHIP, "internal: the device SAH builder returned a malformed tree"); }
+    }
     (void)hipFree(r.d_orig);
     r.d_orig = nullptr;
     ctx->host_packets_stale = true;
-    ctx->bvh_depth = r.depth + 1;
+    ctx->bvh_depth = sah ? r.depth : r.depth + 1;
     ctx->n_flat = nf;
     clk.lap("download + list in front");
-    const bool retopped = sah_top_rebuild(ctx, ctx->lbvh_cluster);
+    const bool retopped = !sah && sah_top_rebuild(ctx, ctx->lbvh_cluster);
     clk.lap("SAH top over clusters");
     int rc = plan_node_placement(ctx);
     clk.lap("node placement + 4-wide nodes");
@@ -1729,7 +1761,7 @@ int pt_upload_triangles(pt_context* ctx) {
     if (ctx->tri_shift != (int32_t)ctx->tris.size())
         return fail(ctx, PT_EINVAL, "triangles were added after the last end_Obj; close the object first (main.cpp:536)");
     const auto t0 = std::chrono::steady_clock::now();
-    if (ctx->bvh_policy == 4) {
+    if (ctx->bvh_policy >= 4) {
         bool done = false;
         int rcd = build_on_device(ctx, &done);
         if (rcd != PT_OK) return rcd;
@@ -2204,6 +2236,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "waves_per_simd") {
         if (value != -1 && (value < 4 || value > 8)) return fail(ctx, PT_EINVAL, "waves_per_simd: -1 automatic (at most 7), 4..8 (kernels that read nodes from global memory)");
         ctx->waves_per_simd = (int)value;
+    } else if (k == "sah_grain") {
+        if (value < 8 || value > (1 << 16)) return fail(ctx, PT_EINVAL, "sah_grain: 8..65536 triangles");
+        ctx->sah_grain = (int)value;
     } else if (k == "lbvh_ploc") {
         if (value != 0 && value != 8 && value != 16 && value != 32) return fail(ctx, PT_EINVAL, "lbvh_ploc: 0 (radix tree), 8, 16 or 32 (PLOC search radius)");
         ctx->lbvh_ploc = (int)value;
@@ -2216,7 +2251,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "cost_binning") {
         ctx->cost_binning = value ? 1 : 0;
     } else if (k == "bvh_policy") {
-        if (value < 0 || value > 4) return fail(ctx, PT_EINVAL, "bvh_policy must be 0..4 (4 = device LBVH)");
+        if (value < 0 || value > 5) return fail(ctx, PT_EINVAL, "bvh_policy must be 0..5 (4 = device LBVH, 5 = the SAH tree built on the device)");
         ctx->bvh_policy = (int)value;
         ctx->tris_uploaded = false;
     } else if (k == "reset_stats") {

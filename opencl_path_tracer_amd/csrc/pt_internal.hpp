@@ -174,6 +174,9 @@ struct LbvhResult {
     int depth = 0;
 };
 hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_all, const int32_t* h_sel, int n, int ploc_radius, hipStream_t stream, LbvhResult* out);
+// the host builder's binned-SAH tree, built on the device (pt_sahdev.hip); *unsupported: a range needs the host's median split
+hipError_t sah_device_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_all, const int32_t* h_sel, int n, int max_leaf, bool force_leaf, float visit_cost, int grain,
+                            hipStream_t stream, LbvhResult* out, bool* unsupported);
 
 struct LaunchConfig {
     int block = 256;                   // traversal_block(node_mode)

@@ -742,6 +742,37 @@ def test_device_bvh_builder(api, oracle, cb_spec, cb_oracle_scene, which, ntris)
     check(sc, fr, "device bvh wavefront %s" % which)
 
 
+@pytest.mark.parametrize("which,ntris,grain", [("cornell", 0, 64), ("cornell", 0, 4096), ("mesh", 6000, 512), ("mesh", 100000, 512), ("mesh", 100000, 64),
+                                               ("mesh", 100000, 8192), ("mesh", 1000000, 512)])
+def test_device_sah_builder_same_tree(api, cb_spec, which, ntris, grain):
+    """bvh_policy 5: the host builder's binned-SAH tree built ON THE DEVICE (pt_sahdev.hip) -- the same nodes (boxes bit for
+    bit, references, order), the same packed triangles, the same depth as bvh_policy 0, whatever the grain that divides
+    the work between the level-synchronous top phase and the one-wave-per-range bottom phase."""
+    from opencl_path_tracer_amd import scenes
+    spec = cb_spec if which == "cornell" else scenes.displaced_grid_mesh(ntris)
+    ref = api.Scene(32, 32)
+    ref.load(spec)
+    assert ref.stat("bvh_on_device") == 0
+    dev = api.Scene(32, 32)
+    dev.set_option("bvh_policy", 5)
+    dev.set_option("sah_grain", grain)
+    dev.load(spec)
+    assert dev.stat("bvh_on_device") == 1
+    for key in ("bvh_nodes", "bvh_depth", "flat_triangles"):
+        assert dev.stat(key) == ref.stat(key), key
+    a, b = ref.debug_bvh(), dev.debug_bvh()
+    assert np.array_equal(a[3], b[3]), "packed triangle order"
+    if not same_bits(a[0], b[0]):
+        bad = np.nonzero((a[0].view(np.uint32) != b[0].view(np.uint32)).any(axis=1))[0]
+        raise AssertionError("nodes differ: %d of %d, first %d\n%s\n%s" % (len(bad), len(a[0]), bad[0], a[0][bad[0]].view(np.uint32), b[0][bad[0]].view(np.uint32)))
+    assert same_bits(a[1], b[1]) and np.array_equal(a[2], b[2]), "packets / meta"
+    if ntris <= 100000:
+        ref.iterations = dev.iterations = 5
+        ref.render(2)
+        dev.render(2)
+        assert same_bits(ref.read_colors(), dev.read_colors())
+
+
 def test_closest_hit_unit_level_mesh(api, oracle):
     """Same unit-level check on the 100k-triangle mesh scene with both builders: device result ==
     exhaustive search == the reference's own traversal on 3,000 random rays."""
