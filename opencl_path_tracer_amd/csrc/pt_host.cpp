@@ -136,7 +136,8 @@ struct pt_context {
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
     int bvh_policy = 0;   // 0/1 host SAH with SAH leaf termination, 2 leaves of <= 4, 3 leaves of <= 8, 4 device LBVH, 5 the SAH tree built on the device
-    int sah_grain = 512;  // device SAH builder: ranges of at most this many triangles are finished by one wave each
+    int sah_grain = 128;  // device SAH builder: ranges of at most this many triangles are finished by one wave each
+    int wide_on_device = 1;  // device-built trees: the 4-wide collapse runs on the device too (0: on the host)
 
     // ---- statistics
     std::vector<EventPair> events;
@@ -1043,6 +1044,24 @@ void compute_cost_boxes_impl(pt_context* ctx) { compute_cost_boxes_from(ctx, nul
 // depth + 2 entries suffice; rounded up to an even count.  Every entry is LDS that bounds the resident waves of the
 // kernels reading nodes from global memory (launch_cfg), so the bound is the exact one, measured on the packed tree.
 int deepest_interior_node(const std::vector<Node64>& nodes) {
+    // Every builder here numbers a child behind its parent (preorder, or merge order counted downwards): one pass in index
+    // order then knows every depth (1M triangles: ~1 ms; the walk below took 8).
+    {
+        std::vector<uint8_t> depth(nodes.size(), 0);
+        int deepest = 0;
+        bool ordered = true;
+        for (size_t i = 0; i < nodes.size() && ordered; ++i) {
+            const int d = depth[i];
+            deepest = std::max(deepest, d);
+            const int32_t kids[2] = {nodes[i].left, nodes[i].right};
+            for (int32_t c : kids)
+                if (c >= 0) {
+                    if ((size_t)c <= i || (size_t)c >= nodes.size() || d >= 254) { ordered = false; break; }
+                    depth[(size_t)c] = (uint8_t)(d + 1);
+                }
+        }
+        if (ordered) return deepest;
+    }
     int deepest = 0;
     std::vector<std::pair<int32_t, int>> todo;
     if (!nodes.empty()) todo.emplace_back(0, 0);
@@ -1145,10 +1164,15 @@ static void group_flat_boxes(pt_context* ctx) {
     }
 }
 
-int plan_node_placement(pt_context* ctx) {
+// d_bvh2: the tree as it is in ctx->nodes, already in device memory (a device-built tree) -- the 4-wide collapse then runs
+// there too (pt_widedev.hip: the same nodes) and *wide_on_device reports that ctx->d_nodes4 is in place.
+int plan_node_placement(pt_context* ctx, const float4* d_bvh2 = nullptr, bool* wide_on_device = nullptr) {
+    PhaseClock clk("node placement");
+    if (wide_on_device) *wide_on_device = false;
     ctx->treelet_nodes = 0;
     group_flat_boxes(ctx);
     ctx->interior_depth = deepest_interior_node(ctx->nodes);
+    clk.lap("list boxes + interior depth");
     if (ctx->interior_depth + 2 > kStackEntries) return fail(ctx, PT_ESCENE, "internal: BVH deeper than the traversal stack");
     const bool fits = whole_tree_fits_lds(ctx->nodes.size(), ctx->orig.size(), ctx->interior_depth, ctx->n_flat);
     if (ctx->treelet != 0 && !fits) ctx->treelet_nodes = reindex_treelet(ctx->nodes, ctx->interior_depth, ctx->treelet);
@@ -1157,9 +1181,26 @@ int plan_node_placement(pt_context* ctx) {
     ctx->nodes4.clear();
     ctx->wide_pending = 0;
     if (ctx->wide_nodes == 2 || (ctx->wide_nodes == 1 && !fits && ctx->treelet_nodes == 0)) {
+        if (d_bvh2 && ctx->treelet_nodes == 0 && ctx->wide_on_device != 0) {
+            float4* d4 = nullptr;
+            int n4 = 0, pending = 0;
+            bool failed = false;
+            PT_HIP(ctx, wide_device_build(d_bvh2, (int)ctx->nodes.size(), ctx->stream, &d4, &n4, &pending, &failed));
+            if (!failed) {
+                if (ctx->d_nodes4) (void)hipFree(ctx->d_nodes4);
+                ctx->d_nodes4 = d4;
+                ctx->nodes4.resize((size_t)n4);          // host copy for the debug getter and the stack sizing
+                ctx->wide_pending = pending;
+                PT_HIP(ctx, hipMemcpy(ctx->nodes4.data(), d4, sizeof(Node4q) * (size_t)n4, hipMemcpyDeviceToHost));
+                if (wide_on_device) *wide_on_device = true;
+            }
+            clk.lap("4-wide nodes (device)");
+            return PT_OK;
+        }
         const unsigned hw = std::thread::hardware_concurrency();
         const int threads = ctx->build_threads > 0 ? ctx->build_threads : (int)std::min(16u, std::max(1u, hw));
         if (!build_wide_nodes(ctx->nodes, &ctx->nodes4, &ctx->wide_pending, threads)) ctx->nodes4.clear();
+        clk.lap("4-wide nodes (host)");
     }
     return PT_OK;
 }
@@ -1731,7 +1772,8 @@ static int build_on_device(pt_context* ctx, bool* done) {
     clk.lap("download + list in front");
     const bool retopped = !sah && sah_top_rebuild(ctx, ctx->lbvh_cluster);
     clk.lap("SAH top over clusters");
-    int rc = plan_node_placement(ctx);
+    bool wide_done = false;
+    int rc = plan_node_placement(ctx, retopped ? nullptr : r.d_nodes, &wide_done);
     clk.lap("node placement + 4-wide nodes");
     if (rc != PT_OK) { drop(); return rc; }
     if (retopped) ctx->bvh_depth = ctx->interior_depth + 1;
@@ -1747,7 +1789,7 @@ static int build_on_device(pt_context* ctx, bool* done) {
         ctx->d_nodes = r.d_nodes;
         if (ctx->treelet_nodes > 0) PT_HIP(ctx, hipMemcpy(ctx->d_nodes, ctx->nodes.data(), sizeof(Node64) * ctx->nodes.size(), hipMemcpyHostToDevice));
     }
-    if ((rc = upload_vec(ctx, &ctx->d_nodes4, ctx->nodes4.data(), sizeof(Node4q) * ctx->nodes4.size())) != PT_OK) return rc;
+    if (!wide_done && (rc = upload_vec(ctx, &ctx->d_nodes4, ctx->nodes4.data(), sizeof(Node4q) * ctx->nodes4.size())) != PT_OK) return rc;
     if ((rc = alloc_stack_overflow(ctx)) != PT_OK) return rc;
     clk.lap("uploads");
     *done = true;
@@ -2236,6 +2278,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "waves_per_simd") {
         if (value != -1 && (value < 4 || value > 8)) return fail(ctx, PT_EINVAL, "waves_per_simd: -1 automatic (at most 7), 4..8 (kernels that read nodes from global memory)");
         ctx->waves_per_simd = (int)value;
+    } else if (k == "wide_on_device") {
+        if (value != 0 && value != 1) return fail(ctx, PT_EINVAL, "wide_on_device: 0 or 1");
+        ctx->wide_on_device = (int)value;
     } else if (k == "sah_grain") {
         if (value < 8 || value > (1 << 16)) return fail(ctx, PT_EINVAL, "sah_grain: 8..65536 triangles");
         ctx->sah_grain = (int)value;

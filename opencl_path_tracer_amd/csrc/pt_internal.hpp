@@ -178,6 +178,9 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_al
 hipError_t sah_device_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_all, const int32_t* h_sel, int n, int max_leaf, bool force_leaf, float visit_cost, int grain,
                             hipStream_t stream, LbvhResult* out, bool* unsupported);
 
+// build_wide_nodes() on the device (pt_widedev.hip): the same 4-wide nodes for a BVH2 that is in device memory
+hipError_t wide_device_build(const float4* d_bvh2, int n_nodes, hipStream_t stream, float4** d_out, int* n_out, int* max_pending, bool* failed);
+
 struct LaunchConfig {
     int block = 256;                   // traversal_block(node_mode)
     size_t lds_bytes = 0;              // traversal_lds_bytes()

@@ -35,7 +35,8 @@ namespace {
 constexpr int NB = 16;                            // BvhBuilder::NB
 constexpr int kBinWords = 13;                     // per (axis, bin): box lo xyz / hi xyz, centroid lo xyz / hi xyz (ordered ints), count
 constexpr int kBinsWords = 3 * NB * kBinWords;    // 624
-constexpr int kTopChunk = 1024;                   // positions per workgroup of the per-position kernels of the top phase
+constexpr int kTopChunk = 256;                    // positions per workgroup of the binning pass of the top phase
+constexpr int kTopSlots = 4;                      // ranges with private bins in LDS per workgroup of that pass
 constexpr int kOrdPosInf = 0x7f800000;            // ordered_int(+inf)
 constexpr int kOrdNegInf = (int)0x807fffffu;      // ordered_int(-inf)
 
@@ -271,20 +272,25 @@ __device__ __forceinline__ Seg child_seg(const WaveLds& w, const Seg& s, const S
 
 // ---- setup ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_sah_prims(const pt_triangle* tris, const int32_t* sel, int n, PBox* pbox, int* idx, int* owner, Counters* cnt) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ int s_red[12];
+    if (threadIdx.x < 12) s_red[threadIdx.x] = (threadIdx.x < 3 || (threadIdx.x >= 6 && threadIdx.x < 9)) ? kOrdPosInf : kOrdNegInf;
+    __syncthreads();
     float v[12];
     for (int j = 0; j < 3; ++j) { v[j] = __builtin_inff(); v[3 + j] = -__builtin_inff(); v[6 + j] = __builtin_inff(); v[9 + j] = -__builtin_inff(); }
-    if (i < n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const PBox b = tri_bounds(tris[sel ? sel[i] : i]);
         pbox[i] = b;
         idx[i] = i;
         owner[i] = 0;
         for (int j = 0; j < 3; ++j) {
-            v[j] = b.lo[j];
-            v[3 + j] = b.hi[j];
-            v[6 + j] = v[9 + j] = 0.5f * (b.lo[j] + b.hi[j]);
+            const float c = 0.5f * (b.lo[j] + b.hi[j]);
+            v[j] = fminf(v[j], b.lo[j]);
+            v[3 + j] = fmaxf(v[3 + j], b.hi[j]);
+            v[6 + j] = fminf(v[6 + j], c);
+            v[9 + j] = fmaxf(v[9 + j], c);
         }
     }
+    // one LDS atomic per wave and component, then one global atomic per block and component
     for (int j = 0; j < 12; ++j) {
         const bool is_min = j < 3 || (j >= 6 && j < 9);
         float x = v[j];
@@ -293,8 +299,13 @@ __global__ void __launch_bounds__(256) k_sah_prims(const pt_triangle* tris, cons
             x = is_min ? fminf(x, y) : fmaxf(x, y);
         }
         if ((threadIdx.x & 63) == 0) {
-            if (is_min) atomicMin(&cnt->root[j], ordered_int(x)); else atomicMax(&cnt->root[j], ordered_int(x));
+            if (is_min) atomicMin(&s_red[j], ordered_int(x)); else atomicMax(&s_red[j], ordered_int(x));
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const bool is_min = threadIdx.x < 3 || (threadIdx.x >= 6 && threadIdx.x < 9);
+        if (is_min) atomicMin(&cnt->root[threadIdx.x], s_red[threadIdx.x]); else atomicMax(&cnt->root[threadIdx.x], s_red[threadIdx.x]);
     }
 }
 
@@ -326,33 +337,49 @@ __global__ void __launch_bounds__(256) k_sah_bins_init(int* gbins, int nsegs) {
 }
 
 // ---- top phase ----------------------------------------------------------------------------------------------------
-// every primitive of an open range into the range's bins; the bin indices are kept for the partition
+// Every primitive of an open range into the range's bins; the bin indices are kept for the partition.  One position per thread;
+// the open ranges a block's 256 positions touch are runs of consecutive positions, each gets a private copy of its bins in
+// LDS (up to kTopSlots of them: ranges are longer than the grain), flushed to the range's bins in global memory at the end.
 __global__ void __launch_bounds__(256) k_top_bin(const PBox* pbox, const int* idx, const int* owner, int n, const SegBin* segbins, int* gbins, uint16_t* packed) {
-    __shared__ int s_bins[kBinsWords];
-    const int base = blockIdx.x * kTopChunk;
-    const int s0 = owner[base];                      // the range most of this block's positions belong to (near the top: all)
-    if (s0 >= 0) bins_reset(s_bins, threadIdx.x, 256);
+    __shared__ int s_bins[kTopSlots][kBinsWords];
+    __shared__ int s_seg[kTopSlots];
+    __shared__ int s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = blockIdx.x * kTopChunk + tid;
+    const int s = pos < n ? owner[pos] : -1;
+    const int prev = (tid == 0 || pos >= n) ? -2 : owner[pos - 1];
+    const bool start = s >= 0 && s != prev;                   // the first position of a run in this block
+    const unsigned long long m = __ballot(start);
+    const int incl = __popcll(m & ((2ull << lane) - 1ull));   // run starts at or before this lane, in this wave
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    for (int w = tid; w < kTopSlots * kBinsWords; w += 256) {
+        const int j = (w % kBinsWords) % kBinWords;
+        (&s_bins[0][0])[w] = j == 12 ? 0 : ((j < 3 || (j >= 6 && j < 9)) ? kOrdPosInf : kOrdNegInf);
+    }
     __syncthreads();
-    for (int j = 0; j < kTopChunk / 256; ++j) {
-        const int pos = base + j * 256 + (int)threadIdx.x;
-        if (pos >= n) break;
-        const int s = owner[pos];
-        if (s < 0) continue;
+    int before = 0, runs = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (k < wave) before += s_wave[k];
+        runs += s_wave[k];
+    }
+    const int slot = before + incl - 1;
+    if (start && slot < kTopSlots) s_seg[slot] = s;
+    if (s >= 0) {
         const SegBin sb = segbins[s];
         const PBox p = pbox[idx[pos]];
         int pk;
-        bin_prim(s == s0 ? s_bins : gbins + (size_t)s * kBinsWords, p, sb, &pk);
+        bin_prim(slot < kTopSlots ? s_bins[slot] : gbins + (size_t)s * kBinsWords, p, sb, &pk);
         packed[pos] = (uint16_t)pk;
     }
     __syncthreads();
-    if (s0 < 0) return;
-    int* g = gbins + (size_t)s0 * kBinsWords;
-    for (int w = threadIdx.x; w < kBinsWords; w += 256) {
-        const int j = w % kBinWords;
-        const int v = s_bins[w];
-        if (j == 12) { if (v != 0) atomicAdd(g + w, v); }
-        else if (j < 3 || (j >= 6 && j < 9)) { if (v != kOrdPosInf) atomicMin(g + w, v); }
-        else { if (v != kOrdNegInf) atomicMax(g + w, v); }
+    const int used = min(runs, kTopSlots);
+    for (int w = tid; w < used * kBinsWords; w += 256) {
+        const int sl = w / kBinsWords, word = w % kBinsWords, j = word % kBinWords;
+        int* g = gbins + (size_t)s_seg[sl] * kBinsWords + word;
+        const int v = s_bins[sl][word];
+        if (j == 12) { if (v != 0) atomicAdd(g, v); }
+        else if (j < 3 || (j >= 6 && j < 9)) { if (v != kOrdPosInf) atomicMin(g, v); }
+        else { if (v != kOrdNegInf) atomicMax(g, v); }
     }
 }
 
@@ -703,7 +730,7 @@ hipError_t sah_device_build(const pt_triangle* h_tris, const int32_t* h_rank, in
     for (int j = 0; j < 12; ++j) h_cnt.root[j] = (j < 3 || (j >= 6 && j < 9)) ? kOrdPosInf : kOrdNegInf;
     SD_HIP(hipMemcpyAsync(d_cnt, &h_cnt, sizeof h_cnt, hipMemcpyHostToDevice, stream));
     const int blocks_n = (n + 255) / 256, blocks_c = (n + kTopChunk - 1) / kTopChunk;
-    hipLaunchKernelGGL(k_sah_prims, dim3(blocks_n), dim3(256), 0, stream, d_tris, d_sel, n, d_pbox, d_idx, d_own, d_cnt);
+    hipLaunchKernelGGL(k_sah_prims, dim3(std::min(blocks_n, 1024)), dim3(256), 0, stream, d_tris, d_sel, n, d_pbox, d_idx, d_own, d_cnt);
     hipLaunchKernelGGL(k_sah_root, dim3(1), dim3(64), 0, stream, n, grain, d_cnt, d_seg, d_sb, d_tasks);
     hipLaunchKernelGGL(k_sah_bins_init, dim3((cap_open * kBinsWords + 255) / 256), dim3(256), 0, stream, d_gbins, cap_open);
     SD_HIP(hipGetLastError());

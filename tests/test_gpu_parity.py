@@ -766,6 +766,9 @@ def test_device_sah_builder_same_tree(api, cb_spec, which, ntris, grain):
         bad = np.nonzero((a[0].view(np.uint32) != b[0].view(np.uint32)).any(axis=1))[0]
         raise AssertionError("nodes differ: %d of %d, first %d\n%s\n%s" % (len(bad), len(a[0]), bad[0], a[0][bad[0]].view(np.uint32), b[0][bad[0]].view(np.uint32)))
     assert same_bits(a[1], b[1]) and np.array_equal(a[2], b[2]), "packets / meta"
+    wa, wb = ref.debug_wide_nodes(), dev.debug_wide_nodes()            # collapsed on the host / on the device (pt_widedev.hip)
+    assert len(wa) == len(wb) and wa.tobytes() == wb.tobytes(), "4-wide nodes"
+    assert ref.stat("wide_pending") == dev.stat("wide_pending")
     if ntris <= 100000:
         ref.iterations = dev.iterations = 5
         ref.render(2)

@@ -28,7 +28,12 @@ for name, grain in cases:
     same_order = np.array_equal(a[3], b[3])
     an, bn = a[0].view(np.uint32), b[0].view(np.uint32)
     same_nodes = an.shape == bn.shape and np.array_equal(an, bn)
-    print("   same order %s  same nodes %s" % (same_order, same_nodes), flush=True)
+    wa, wb = ref.debug_wide_nodes(), dev.debug_wide_nodes()
+    same_wide = len(wa) == len(wb) and wa.tobytes() == wb.tobytes()
+    print("   same order %s  same nodes %s  4-wide nodes %d / %d same %s" % (same_order, same_nodes, len(wa), len(wb), same_wide), flush=True)
+    if not same_wide and len(wa) == len(wb) and len(wa):
+        bad = [i for i in range(len(wa)) if wa[i].tobytes() != wb[i].tobytes()]
+        print("   %d wide nodes differ, first %d:\n%s\n%s" % (len(bad), bad[0], wa[bad[0]], wb[bad[0]]), flush=True)
     if not same_nodes and an.shape == bn.shape:
         bad = np.nonzero((an != bn).any(axis=1))[0]
         print("   %d nodes differ, first %d:\n%s\n%s" % (len(bad), bad[0], a[0][bad[0]], b[0][bad[0]]), flush=True)
