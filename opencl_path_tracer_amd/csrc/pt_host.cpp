@@ -1667,53 +1667,99 @@ static bool sah_top_rebuild(pt_context* ctx, int cluster) {
 }
 
 // bvh_policy 4: build the tree on the device (pt_lbvh.hip); host copies are kept for the debug getters
+// The big-triangle list of select_flat_list(), from the half areas of ALL triangles (add order) and a callback for the
+// bounds of everything but the candidates: the same choice, without the host builder's primitive array.
+static int choose_flat_list(const pt_context* ctx, const std::vector<float>& area, const std::function<int(const std::vector<int32_t>&, Aabb*)>& rest_box,
+                            std::vector<int32_t>* flat) {
+    flat->clear();
+    const size_t n = area.size();
+    if (ctx->flat_list <= 0 || n == 0) return PT_OK;
+    const int threads = host_threads(ctx);
+    const size_t cand = std::min<size_t>((size_t)ctx->flat_list, n);
+    auto bigger = [&](size_t a, size_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); };
+    // the cand biggest in order (ties: add order): per chunk, then merged -- `bigger` is a total order, so any grouping agrees
+    const size_t chunks = std::max<size_t>(1, std::min<size_t>((size_t)threads, n / 65536 + 1));
+    std::vector<std::vector<size_t>> part(chunks);
+    parallel_for(chunks, 1, threads, [&](size_t cb, size_t ce) {
+        for (size_t c = cb; c < ce; ++c) {
+            std::vector<size_t>& top = part[c];
+            top.reserve(cand + 1);
+            const size_t lo = n * c / chunks, hi = n * (c + 1) / chunks;
+            for (size_t i = lo; i < hi; ++i) {
+                if (top.size() == cand && !bigger(i, top.back())) continue;
+                top.insert(std::upper_bound(top.begin(), top.end(), i, bigger), i);
+                if (top.size() > cand) top.pop_back();
+            }
+        }
+    });
+    std::vector<size_t> top;
+    for (const std::vector<size_t>& p : part) top.insert(top.end(), p.begin(), p.end());
+    std::sort(top.begin(), top.end(), bigger);
+    top.resize(cand);
+    std::vector<int32_t> top32(cand);
+    for (size_t k = 0; k < cand; ++k) top32[k] = (int32_t)top[k];
+    Aabb tail;
+    int rc = rest_box(top32, &tail);
+    if (rc != PT_OK) return rc;
+    std::vector<Aabb> rest(cand + 1);                 // rest[k] = box of top[k..] and all the others
+    rest[cand] = tail;
+    for (size_t k = cand; k-- > 0;) { tail.grow(padded_bounds(ctx->tris[top[k]])); rest[k] = tail; }
+    for (size_t m = cand; m > 0; --m) {               // the largest m such that each of the m biggest is >= 1/16 of the box around all the others
+        const float smallest = area[top[m - 1]], others = rest[m].half_area();
+        if (smallest >= others * (1.0f / 16.0f)) {
+            flat->assign(top32.begin(), top32.begin() + (std::ptrdiff_t)m);
+            std::sort(flat->begin(), flat->end());    // add order
+            break;
+        }
+    }
+    return PT_OK;
+}
+
 static int build_on_device(pt_context* ctx, bool* done) {
     *done = false;
     PhaseClock clk("pt_upload_triangles/device");
     const int n = (int)ctx->tris.size();
     if (!ctx->has_device || n <= 2 * kMaxLeaf) return PT_OK;
-    {
-        std::atomic<bool> all_finite(true);
-        parallel_for((size_t)n, 1 << 14, host_threads(ctx), [&](size_t b, size_t e) {
-            bool ok = true;
-            for (size_t i = b; i < e && ok; ++i) {
-                const pt_triangle& t = ctx->tris[i];
-                for (int a = 0; a < 3; ++a) ok = ok && std::isfinite(t.r1.s[a]) && std::isfinite(t.r2.s[a]) && std::isfinite(t.r3.s[a]);
-            }
-            if (!ok) all_finite.store(false);
-        });
-        if (!all_finite.load()) return PT_OK;   // host path handles those
-    }
     PT_HIP(ctx, hipSetDevice(ctx->device));
-    // the big-triangle list is chosen on the host (one pass over the boxes); the device builds the tree of the rest
-    const int threads = host_threads(ctx);
-    std::vector<BuildPrim> prims((size_t)n);
-    parallel_for((size_t)n, 1 << 14, threads, [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) { prims[i].box = padded_bounds(ctx->tris[i]); prims[i].tri = (int32_t)i; }
-    });
-    const std::vector<int32_t> flat = select_flat_list(ctx, prims);
+    // The triangles go to the device as they are; the areas of their padded bounds come back for the big-triangle list,
+    // which is chosen on the host (<= 32 entries) from bounds the device reduces.
+    DeviceStage st;
+    struct StageGuard {
+        DeviceStage* s;
+        ~StageGuard() { stage_free(s); }
+    } guard{&st};
+    std::vector<float> area((size_t)n);
+    int nonfinite = 0;
+    PT_HIP(ctx, stage_upload(ctx->tris.data(), ctx->enc_rank.data(), n, ctx->stream, &st, area.data(), &nonfinite));
+    if (nonfinite) return PT_OK;                // the host path handles those
+    clk.lap("upload + areas");
+    std::vector<int32_t> flat;
+    int frc = choose_flat_list(ctx, area, [&](const std::vector<int32_t>& top, Aabb* box) {
+        float b[6];
+        PT_HIP(ctx, stage_rest_box(st, top.data(), (int)top.size(), ctx->stream, b));
+        for (int a = 0; a < 3; ++a) { box->lo[a] = b[a]; box->hi[a] = b[3 + a]; }
+        return (int)PT_OK;
+    }, &flat);
+    if (frc != PT_OK) return frc;
+    std::vector<float>().swap(area);
     const int nf = (int)flat.size(), ns = n - nf;
     if (ns <= 2 * kMaxLeaf) return PT_OK;
-    // what goes into the tree: an index list (the device gathers; the triangles are uploaded once, as they are)
-    std::vector<int32_t> sel;
-    if (nf > 0) {
-        sel.resize((size_t)ns);
-        parallel_for((size_t)ns, 1 << 15, threads, [&](size_t b, size_t e) { for (size_t k = b; k < e; ++k) sel[k] = prims[k].tri; });
-    }
-    std::vector<BuildPrim>().swap(prims);
-    clk.lap("boxes + big-triangle list");
+    if (nf > 0) PT_HIP(ctx, stage_select(st, flat.data(), nf, ctx->stream));
+    const int32_t* d_sel = nf > 0 ? st.d_sel : nullptr;
+    const int threads = host_threads(ctx);
+    clk.lap("big-triangle list");
     LbvhResult r;
     const bool sah = ctx->bvh_policy == 5;
     if (sah) {                                  // the host builder's tree (policy 0), node for node; the host builds what the device cannot
         bool unsupported = false;
-        PT_HIP(ctx, sah_device_build(ctx->tris.data(), ctx->enc_rank.data(), n, nf > 0 ? sel.data() : nullptr, ns, 4, false, (float)ctx->sah_visit_cost * 0.1f, ctx->sah_grain,
-                                     ctx->stream, &r, &unsupported));
+        PT_HIP(ctx, sah_device_build(st.d_tris, st.d_rank, n, d_sel, ns, 4, false, (float)ctx->sah_visit_cost * 0.1f, ctx->sah_grain, ctx->stream, &r, &unsupported));
         if (unsupported) return PT_OK;
         clk.lap("sah_device_build");
     } else {
-        PT_HIP(ctx, lbvh_build(ctx->tris.data(), ctx->enc_rank.data(), n, nf > 0 ? sel.data() : nullptr, ns, ctx->lbvh_ploc, ctx->stream, &r));
+        PT_HIP(ctx, lbvh_build(st.d_tris, st.d_rank, n, d_sel, ns, ctx->lbvh_ploc, ctx->stream, &r));
         clk.lap("lbvh_build");
     }
+    stage_free(&st);
     auto drop = [&]() { (void)hipFree(r.d_nodes); (void)hipFree(r.d_tris); (void)hipFree(r.d_meta); (void)hipFree(r.d_orig); };
     if (!sah && r.depth + 5 > kStackEntries) {  // deeper than the traversal stack: let the host builder do it
         drop();

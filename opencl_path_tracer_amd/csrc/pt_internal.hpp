@@ -173,9 +173,23 @@ struct LbvhResult {
     int32_t* d_orig = nullptr;
     int depth = 0;
 };
-hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_all, const int32_t* h_sel, int n, int ploc_radius, hipStream_t stream, LbvhResult* out);
+// all triangles of a scene in device memory, for the device builders (pt_sahdev.hip: stage_*)
+struct DeviceStage {
+    char* base = nullptr;            // the one allocation behind the pointers below
+    pt_triangle* d_tris = nullptr;   // add order
+    int32_t* d_rank = nullptr;       // encounter ranks, add order
+    int32_t* d_sel = nullptr;        // add-order indices of the triangles that go into the tree (stage_select)
+    float* d_area = nullptr;         // half area of every triangle's padded bounds
+    int* d_misc = nullptr;
+    int n = 0;
+};
+hipError_t stage_upload(const pt_triangle* h_tris, const int32_t* h_rank, int n, hipStream_t stream, DeviceStage* st, float* h_area, int* nonfinite);
+hipError_t stage_rest_box(const DeviceStage& st, const int32_t* h_top, int cand, hipStream_t stream, float box[6]);
+hipError_t stage_select(const DeviceStage& st, const int32_t* h_flat, int nf, hipStream_t stream);
+void stage_free(DeviceStage* st);
+hipError_t lbvh_build(const pt_triangle* d_tris, const int32_t* d_rank, int n_all, const int32_t* d_sel, int n, int ploc_radius, hipStream_t stream, LbvhResult* out);
 // the host builder's binned-SAH tree, built on the device (pt_sahdev.hip); *unsupported: a range needs the host's median split
-hipError_t sah_device_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_all, const int32_t* h_sel, int n, int max_leaf, bool force_leaf, float visit_cost, int grain,
+hipError_t sah_device_build(const pt_triangle* d_tris, const int32_t* d_rank, int n_all, const int32_t* d_sel, int n, int max_leaf, bool force_leaf, float visit_cost, int grain,
                             hipStream_t stream, LbvhResult* out, bool* unsupported);
 
 // build_wide_nodes() on the device (pt_widedev.hip): the same 4-wide nodes for a BVH2 that is in device memory

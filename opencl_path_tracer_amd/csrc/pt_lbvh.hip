@@ -426,13 +426,11 @@ __global__ void __launch_bounds__(256) k_pack(const unsigned long long* keys, in
 
 // Builds the tree for n (> kMaxLeaf) triangles given in add order on the HOST; every step after the
 // upload runs on the device.  On success the caller owns out->* (hipFree).
-// h_tris / h_rank: ALL n_all triangles in add order; h_sel: the n of them that go into the tree (null: all, n == n_all).  The
+// d_tris / d_rank: ALL n_all triangles in add order, in device memory (stage_upload); d_sel: the n of them that go into the tree
+// (null: all, n == n_all).  The
 // packets / meta / orig arrays are emitted for n_all triangles with the tree's behind the first n_all - n slots, which the
 // caller fills (the big-triangle list); leaf references count from there.
-hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_all, const int32_t* h_sel, int n, int ploc_radius, hipStream_t stream, LbvhResult* out) {
-    pt_triangle* d_tris = nullptr;
-    int32_t* d_rank = nullptr;
-    int32_t* d_sel = nullptr;
+hipError_t lbvh_build(const pt_triangle* d_tris, const int32_t* d_rank, int n_all, const int32_t* d_sel, int n, int ploc_radius, hipStream_t stream, LbvhResult* out) {
     const int nf = n_all - n;
     Box *d_pbox = nullptr, *d_nbox = nullptr;
     unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
@@ -449,7 +447,7 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_al
     TriMeta* d_meta = nullptr;
     int32_t* d_orig = nullptr;
     auto cleanup = [&]() {
-        void* ptrs[] = {d_tris, d_rank, d_sel, d_pbox, d_nbox, d_keys, d_keys2, d_rnodes, d_pint, d_pleaf, d_arr, d_flags, d_oidx, d_misc, d_temp,
+        void* ptrs[] = {d_pbox, d_nbox, d_keys, d_keys2, d_rnodes, d_pint, d_pleaf, d_arr, d_flags, d_oidx, d_misc, d_temp,
                         d_cidA, d_cidB, d_nn, d_leader, d_keep, d_lscan, d_kscan, d_count, d_dfs, d_pleaf2, d_cboxA, d_cboxB, d_keys3};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     };
@@ -463,14 +461,6 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_al
     const int ni = n - 1;
     const int blocks_n = (n + 255) / 256, blocks_i = (ni + 255) / 256;
     PhaseClock clk("device bvh");
-    LB_HIP(hipMalloc((void**)&d_tris, sizeof(pt_triangle) * (size_t)n_all));
-    LB_HIP(hipMalloc((void**)&d_rank, sizeof(int32_t) * (size_t)n_all));
-    LB_HIP(hipMemcpyAsync(d_tris, h_tris, sizeof(pt_triangle) * (size_t)n_all, hipMemcpyHostToDevice, stream));
-    LB_HIP(hipMemcpyAsync(d_rank, h_rank, sizeof(int32_t) * (size_t)n_all, hipMemcpyHostToDevice, stream));
-    if (h_sel) {
-        LB_HIP(hipMalloc((void**)&d_sel, sizeof(int32_t) * (size_t)n));
-        LB_HIP(hipMemcpyAsync(d_sel, h_sel, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream));
-    }
     LB_HIP(hipMalloc((void**)&d_pbox, sizeof(Box) * (size_t)n));
     LB_HIP(hipMalloc((void**)&d_nbox, sizeof(Box) * (size_t)ni));
     LB_HIP(hipMalloc((void**)&d_keys, sizeof(unsigned long long) * (size_t)n));
@@ -504,7 +494,7 @@ hipError_t lbvh_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_al
     LB_HIP(hipMalloc(&d_temp, std::max(temp_bytes, scan_bytes) + 256));
     LB_HIP(hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys2, n, 0, 64, stream));
     const unsigned long long* keys = d_keys2;
-    if (clk.on) { LB_HIP(hipStreamSynchronize(stream)); clk.lap("upload + boxes + morton + sort"); }
+    if (clk.on) { LB_HIP(hipStreamSynchronize(stream)); clk.lap("boxes + morton + sort"); }
     if (ploc_radius > 0) {
         LB_HIP(hipMalloc((void**)&d_cidA, sizeof(int) * (size_t)n));
         LB_HIP(hipMalloc((void**)&d_cidB, sizeof(int) * (size_t)n));

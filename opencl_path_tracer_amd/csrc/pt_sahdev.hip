@@ -164,12 +164,11 @@ __device__ __forceinline__ void bin_prim(int* bins, const PBox& p, const SegBin&
 }
 
 // ---- the split decision of one range, by one wave -------------------------------------------------------------------
-// LDS the wave works in: its bins, the sweeps' results, and the two children.
+// LDS the wave works in: its bins and the two children.
 struct WaveLds {
     int bins[kBinsWords];
-    float area[2][3 * NB];          // [0]: la (bins 0..k), [1]: ra (bins k..15)
-    int cnt[2][3 * NB];
     float child[2][12];             // per side: box lo, hi, centroid lo, hi
+    int nl;                         // primitives on the left side
 };
 
 struct SplitOut {
@@ -177,38 +176,71 @@ struct SplitOut {
     bool bad;                       // the host would split at the median here
 };
 
-// All 64 lanes call this with the same arguments; `w.bins` is filled.  Needs __syncthreads()-free wave-synchronous LDS use:
-// the workgroup IS the wave wherever this is called (64 threads), so __syncthreads() is a wave barrier.
+// lane i takes the value of lane i - D (CTRL = 0x110 + D, row_shr) or i + D (0x100 + D, row_shl) of its row of 16 lanes; a lane
+// whose source lies outside the row keeps `old`
+template <int CTRL> __device__ __forceinline__ float dpp_f(float old, float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xf, 0xf, false); }
+
+struct BinAcc {                     // what the host's sweep carries: the box of the bins so far, their centroid bounds, the count
+    float lo[3], hi[3], clo[3], chi[3];
+    int cnt;
+};
+template <int CTRL> __device__ __forceinline__ void scan_step(BinAcc& x) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        x.lo[j] = fminf(x.lo[j], dpp_f<CTRL>(x.lo[j], x.lo[j]));
+        x.hi[j] = fmaxf(x.hi[j], dpp_f<CTRL>(x.hi[j], x.hi[j]));
+        x.clo[j] = fminf(x.clo[j], dpp_f<CTRL>(x.clo[j], x.clo[j]));
+        x.chi[j] = fmaxf(x.chi[j], dpp_f<CTRL>(x.chi[j], x.chi[j]));
+    }
+    x.cnt += dpp_i<CTRL>(0, x.cnt);
+}
+
+// All 64 lanes call this with the same arguments; `w.bins` is filled and comes back EMPTY (ready for the next range).  The
+// workgroup IS the wave wherever this is called (64 threads), so __syncthreads() is a wave barrier.
+// Lane a * 16 + k holds bin k of axis a; the host's prefix / suffix sweeps over the 16 bins of an axis are inclusive scans
+// along a row of 16 lanes (min / max / integer sums: any order gives the host's values).
 __device__ SplitOut eval_split(WaveLds& w, const Seg& s, int open, int max_leaf, bool force_leaf, float visit_cost) {
     const int lane = threadIdx.x & 63;
     const int n = s.hi - s.lo;
-    if (lane < 6) {                                  // lane = axis * 2 + direction: the prefix / suffix sweep of BvhBuilder::split
-        const int a = lane >> 1, dir = lane & 1;
-        float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-        int c = 0;
-        for (int step = 0; step < NB; ++step) {
-            const int k = dir ? NB - 1 - step : step;
-            const int* b = w.bins + (a * NB + k) * kBinWords;
-            for (int j = 0; j < 3; ++j) {
-                lo[j] = fminf(lo[j], from_ordered_int(b[j]));
-                hi[j] = fmaxf(hi[j], from_ordered_int(b[3 + j]));
-            }
-            c += b[12];
-            w.area[dir][a * NB + k] = half_area6(lo, hi);
-            w.cnt[dir][a * NB + k] = c;
+    BinAcc pre;
+    {
+        int* b = w.bins + min(lane, 3 * NB - 1) * kBinWords;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            pre.lo[j] = from_ordered_int(b[j]);
+            pre.hi[j] = from_ordered_int(b[3 + j]);
+            pre.clo[j] = from_ordered_int(b[6 + j]);
+            pre.chi[j] = from_ordered_int(b[9 + j]);
+        }
+        pre.cnt = b[12];
+        if (lane < 3 * NB) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { b[j] = kOrdPosInf; b[3 + j] = kOrdNegInf; b[6 + j] = kOrdPosInf; b[9 + j] = kOrdNegInf; }
+            b[12] = 0;
         }
     }
-    __syncthreads();
+    BinAcc suf = pre;
+    scan_step<0x111>(pre);
+    scan_step<0x112>(pre);
+    scan_step<0x114>(pre);
+    scan_step<0x118>(pre);
+    scan_step<0x101>(suf);
+    scan_step<0x102>(suf);
+    scan_step<0x104>(suf);
+    scan_step<0x108>(suf);
+    const float la = half_area6(pre.lo, pre.hi), ra = half_area6(suf.lo, suf.hi);
+    const float ra_next = dpp_f<0x101>(0.f, ra);                   // the suffix from bin k + 1 on
+    const int rc_next = dpp_i<0x101>(0, suf.cnt);
     float cost = __builtin_inff();
     bool valid = false;
-    if (lane < 3 * NB) {
+    {
         const int a = lane / NB, k = lane % NB;
-        if (k < NB - 1 && ((open >> a) & 1)) {
-            const int lc = w.cnt[0][a * NB + k], rc = w.cnt[1][a * NB + k + 1];
-            if (lc != 0 && rc != 0) {
-                const float t = w.area[0][a * NB + k] * (float)lc + w.area[1][a * NB + k + 1] * (float)rc;
-                if (t < __builtin_inff()) { cost = t; valid = true; }      // (the host's `cost < best_cost` never takes inf or NaN)
-            }
+        if (lane < 3 * NB && k < NB - 1 && ((open >> a) & 1) && pre.cnt != 0 && rc_next != 0) {
+            const float t = la * (float)pre.cnt + ra_next * (float)rc_next;
+            if (t < __builtin_inff()) { cost = t; valid = true; }      // (the host's `cost < best_cost` never takes inf or NaN)
         }
     }
     float best = cost;
@@ -226,27 +258,22 @@ __device__ SplitOut eval_split(WaveLds& w, const Seg& s, int open, int max_leaf,
     const float best_cost = pick >= 0 ? best : __builtin_inff();
     if (n <= max_leaf && (force_leaf || !(best_cost + visit_cost * area < leaf_cost))) return o;      // a leaf
     if (pick < 0) { o.bad = true; return o; }
-    o.axis = pick / NB;
-    o.bin = pick % NB;
-    o.nl = w.cnt[0][pick];
-    const int big = max(o.nl, n - o.nl);
-    if (s.depth + 1 + need_levels(big) > kMaxDepth) { o.bad = true; o.axis = -1; return o; }
-    if (lane < 2) {                                  // the children's bounds: the union of the bins on either side
-        float v[12];
-        for (int j = 0; j < 3; ++j) { v[j] = __builtin_inff(); v[3 + j] = -__builtin_inff(); v[6 + j] = __builtin_inff(); v[9 + j] = -__builtin_inff(); }
-        const int k0 = lane == 0 ? 0 : o.bin + 1, k1 = lane == 0 ? o.bin : NB - 1;
-        for (int k = k0; k <= k1; ++k) {
-            const int* b = w.bins + (o.axis * NB + k) * kBinWords;
-            for (int j = 0; j < 3; ++j) {
-                v[j] = fminf(v[j], from_ordered_int(b[j]));
-                v[3 + j] = fmaxf(v[3 + j], from_ordered_int(b[3 + j]));
-                v[6 + j] = fminf(v[6 + j], from_ordered_int(b[6 + j]));
-                v[9 + j] = fmaxf(v[9 + j], from_ordered_int(b[9 + j]));
-            }
-        }
-        for (int j = 0; j < 12; ++j) w.child[lane][j] = v[j];
+    // the children's bounds: the union of the bins on either side = the prefix at the split bin, the suffix behind it
+    if (lane == pick) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { w.child[0][j] = pre.lo[j]; w.child[0][3 + j] = pre.hi[j]; w.child[0][6 + j] = pre.clo[j]; w.child[0][9 + j] = pre.chi[j]; }
+        w.nl = pre.cnt;
+    }
+    if (lane == pick + 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { w.child[1][j] = suf.lo[j]; w.child[1][3 + j] = suf.hi[j]; w.child[1][6 + j] = suf.clo[j]; w.child[1][9 + j] = suf.chi[j]; }
     }
     __syncthreads();
+    o.axis = pick / NB;
+    o.bin = pick % NB;
+    o.nl = w.nl;
+    const int big = max(o.nl, n - o.nl);
+    if (s.depth + 1 + need_levels(big) > kMaxDepth) { o.bad = true; o.axis = -1; return o; }
     return o;
 }
 
@@ -495,6 +522,7 @@ __global__ void __launch_bounds__(64) k_sah_bottom(const PBox* pbox, int* idx, i
         stack[0].slot = -1;                           // (the task's own slot is a TOP node's: the splice resolves that one)
     }
     sp = 1;
+    bins_reset(w.bins, lane, 64);                     // (eval_split hands them back empty)
     __syncthreads();
     Node64* mine = tnodes + stack[0].lo;              // at most n - 1 interior nodes for n primitives: the task's own slice
     int made = 0, deepest = 0;
@@ -513,8 +541,6 @@ __global__ void __launch_bounds__(64) k_sah_bottom(const PBox* pbox, int* idx, i
         int my_idx = 0;
         if (n > 1) {
             const SegBin sb = segbin_of(s.cb);
-            bins_reset(w.bins, lane, 64);
-            __syncthreads();
             for (int i = s.lo + lane; i < s.hi; i += 64) {
                 my_idx = idx[i];
                 const PBox p = pbox[my_idx];
@@ -651,11 +677,11 @@ inline size_t round256(size_t x) { return (x + 255) & ~size_t(255); }
 
 }  // namespace
 
-// Builds the host builder's tree for the n triangles h_sel selects (null: all n_all) of h_tris, on the device.  The packets / meta
+// Builds the host builder's tree for the n triangles d_sel selects (null: all n_all) of d_tris (device memory: stage_upload).  The packets / meta
 // / orig arrays are emitted for n_all triangles with the tree's behind the first n_all - n slots (the big-triangle list, which
 // the caller fills); leaf references count from there.  *unsupported is set (and nothing returned) when a range needs the
 // host builder's median split.  On success the caller owns out->* (hipFree).
-hipError_t sah_device_build(const pt_triangle* h_tris, const int32_t* h_rank, int n_all, const int32_t* h_sel, int n, int max_leaf, bool force_leaf, float visit_cost, int grain,
+hipError_t sah_device_build(const pt_triangle* d_tris, const int32_t* d_rank, int n_all, const int32_t* d_sel, int n, int max_leaf, bool force_leaf, float visit_cost, int grain,
                             hipStream_t stream, LbvhResult* out, bool* unsupported) {
     *unsupported = false;
     PhaseClock clk("device sah");
@@ -667,7 +693,6 @@ hipError_t sah_device_build(const pt_triangle* h_tris, const int32_t* h_rank, in
     // one allocation for everything that is scratch
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t at = off; off += round256(bytes); return at; };
-    const size_t o_tris = carve(sizeof(pt_triangle) * (size_t)n_all), o_rank = carve(sizeof(int32_t) * (size_t)n_all), o_sel = carve(sizeof(int32_t) * (size_t)n);
     const size_t o_pbox = carve(sizeof(PBox) * (size_t)n), o_idxA = carve(sizeof(int) * (size_t)n), o_idxB = carve(sizeof(int) * (size_t)n);
     const size_t o_ownA = carve(sizeof(int) * (size_t)n), o_ownB = carve(sizeof(int) * (size_t)n), o_packed = carve(sizeof(uint16_t) * (size_t)n);
     const size_t o_flags = carve(sizeof(int) * (size_t)n), o_scan = carve(sizeof(int) * (size_t)n);
@@ -694,9 +719,6 @@ hipError_t sah_device_build(const pt_triangle* h_tris, const int32_t* h_rank, in
     SD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, n, stream));
     const size_t o_temp = carve(scan_bytes + 256);
     SD_HIP(hipMalloc((void**)&d_all, off));
-    pt_triangle* d_tris = reinterpret_cast<pt_triangle*>(d_all + o_tris);
-    int32_t* d_rank = reinterpret_cast<int32_t*>(d_all + o_rank);
-    int32_t* d_sel = h_sel ? reinterpret_cast<int32_t*>(d_all + o_sel) : nullptr;
     PBox* d_pbox = reinterpret_cast<PBox*>(d_all + o_pbox);
     int* d_idx = reinterpret_cast<int*>(d_all + o_idxA);
     int* d_idx2 = reinterpret_cast<int*>(d_all + o_idxB);
@@ -722,9 +744,6 @@ hipError_t sah_device_build(const pt_triangle* h_tris, const int32_t* h_rank, in
     Counters* d_cnt = reinterpret_cast<Counters*>(d_all + o_cnt);
     void* d_temp = d_all + o_temp;
 
-    SD_HIP(hipMemcpyAsync(d_tris, h_tris, sizeof(pt_triangle) * (size_t)n_all, hipMemcpyHostToDevice, stream));
-    SD_HIP(hipMemcpyAsync(d_rank, h_rank, sizeof(int32_t) * (size_t)n_all, hipMemcpyHostToDevice, stream));
-    if (h_sel) SD_HIP(hipMemcpyAsync(d_sel, h_sel, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream));
     Counters h_cnt;
     std::memset(&h_cnt, 0, sizeof h_cnt);
     for (int j = 0; j < 12; ++j) h_cnt.root[j] = (j < 3 || (j >= 6 && j < 9)) ? kOrdPosInf : kOrdNegInf;
@@ -734,7 +753,7 @@ hipError_t sah_device_build(const pt_triangle* h_tris, const int32_t* h_rank, in
     hipLaunchKernelGGL(k_sah_root, dim3(1), dim3(64), 0, stream, n, grain, d_cnt, d_seg, d_sb, d_tasks);
     hipLaunchKernelGGL(k_sah_bins_init, dim3((cap_open * kBinsWords + 255) / 256), dim3(256), 0, stream, d_gbins, cap_open);
     SD_HIP(hipGetLastError());
-    if (clk.on) { SD_HIP(hipStreamSynchronize(stream)); clk.lap("upload + boxes"); }
+    if (clk.on) { SD_HIP(hipStreamSynchronize(stream)); clk.lap("boxes"); }
 
     int nsegs = n > grain ? 1 : 0, levels = 0;
     while (nsegs > 0) {
@@ -816,6 +835,131 @@ hipError_t sah_device_build(const pt_triangle* h_tris, const int32_t* h_rank, in
     out->d_orig = d_orig;
     out->depth = h_cnt.deepest;
     return hipSuccess;
+}
+
+
+// ---- staging for the device builders: the triangles in device memory, and the big-triangle list chosen there ----------------
+namespace {
+
+__global__ void __launch_bounds__(256) k_stage_area(const pt_triangle* tris, int n, float* area, int* nonfinite) {
+    int bad = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const pt_triangle t = tris[i];
+        bool ok = true;
+        for (int a = 0; a < 3; ++a) ok = ok && isfinite(t.r1.s[a]) && isfinite(t.r2.s[a]) && isfinite(t.r3.s[a]);
+        const PBox b = tri_bounds(t);
+        area[i] = half_area6(b.lo, b.hi);
+        if (!ok) bad = 1;
+    }
+    if (__ballot(bad != 0) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(nonfinite, 1);
+}
+
+// bounds of all triangles but the `cand` listed ones (ordered ints in box[0..5], preset to +inf / -inf)
+__global__ void __launch_bounds__(256) k_stage_rest_box(const pt_triangle* tris, int n, const int32_t* top, int cand, int* box) {
+    __shared__ int s_top[32];
+    __shared__ int s_red[6];
+    if (threadIdx.x < 32) s_top[threadIdx.x] = (int)threadIdx.x < cand ? top[threadIdx.x] : -1;
+    if (threadIdx.x < 6) s_red[threadIdx.x] = threadIdx.x < 3 ? kOrdPosInf : kOrdNegInf;
+    __syncthreads();
+    float v[6] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        bool listed = false;
+        for (int k = 0; k < cand; ++k) listed = listed || s_top[k] == i;
+        if (listed) continue;
+        const PBox b = tri_bounds(tris[i]);
+        for (int a = 0; a < 3; ++a) {
+            v[a] = fminf(v[a], b.lo[a]);
+            v[3 + a] = fmaxf(v[3 + a], b.hi[a]);
+        }
+    }
+    for (int j = 0; j < 6; ++j) {
+        float x = v[j];
+        for (int off = 32; off > 0; off >>= 1) {
+            const float y = __shfl_xor(x, off, 64);
+            x = j < 3 ? fminf(x, y) : fmaxf(x, y);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (j < 3) atomicMin(&s_red[j], ordered_int(x)); else atomicMax(&s_red[j], ordered_int(x));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        if (threadIdx.x < 3) atomicMin(&box[threadIdx.x], s_red[threadIdx.x]); else atomicMax(&box[threadIdx.x], s_red[threadIdx.x]);
+    }
+}
+
+// sel[k] = add-order index of the k-th triangle that is NOT on the list (flat: sorted ascending)
+__global__ void __launch_bounds__(256) k_stage_select(int ns, const int32_t* flat, int nf, int32_t* sel) {
+    __shared__ int s_flat[32];
+    if (threadIdx.x < 32) s_flat[threadIdx.x] = (int)threadIdx.x < nf ? flat[threadIdx.x] : 0x7fffffff;
+    __syncthreads();
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns) return;
+    int j = 0;
+    while (j < nf && s_flat[j] - j <= k) ++j;
+    sel[k] = k + j;
+}
+
+}  // namespace
+
+hipError_t stage_upload(const pt_triangle* h_tris, const int32_t* h_rank, int n, hipStream_t stream, DeviceStage* st, float* h_area, int* nonfinite) {
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t at = off; off += round256(bytes); return at; };
+    const size_t o_tris = carve(sizeof(pt_triangle) * (size_t)n), o_rank = carve(sizeof(int32_t) * (size_t)n), o_sel = carve(sizeof(int32_t) * (size_t)n);
+    const size_t o_area = carve(sizeof(float) * (size_t)n), o_misc = carve(sizeof(int) * 48);
+    char* base = nullptr;
+    hipError_t e = hipMalloc((void**)&base, off);
+    if (e != hipSuccess) return e;
+    st->base = base;
+    st->d_tris = reinterpret_cast<pt_triangle*>(base + o_tris);
+    st->d_rank = reinterpret_cast<int32_t*>(base + o_rank);
+    st->d_sel = reinterpret_cast<int32_t*>(base + o_sel);
+    st->d_area = reinterpret_cast<float*>(base + o_area);
+    st->d_misc = reinterpret_cast<int*>(base + o_misc);
+    st->n = n;
+    int init[48];
+    for (int j = 0; j < 48; ++j) init[j] = 0;
+    for (int j = 0; j < 3; ++j) { init[8 + j] = kOrdPosInf; init[11 + j] = kOrdNegInf; }
+    if ((e = hipMemcpyAsync(st->d_tris, h_tris, sizeof(pt_triangle) * (size_t)n, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(st->d_rank, h_rank, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(st->d_misc, init, sizeof init, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_stage_area, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, stream, st->d_tris, n, st->d_area, st->d_misc);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(h_area, st->d_area, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(nonfinite, st->d_misc, sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    return hipStreamSynchronize(stream);
+}
+
+// bounds (lo xyz, hi xyz) of all staged triangles except the `cand` (<= 32) listed in h_top
+hipError_t stage_rest_box(const DeviceStage& st, const int32_t* h_top, int cand, hipStream_t stream, float box[6]) {
+    hipError_t e;
+    int32_t* d_top = reinterpret_cast<int32_t*>(st.d_misc + 16);
+    if (cand > 0 && (e = hipMemcpyAsync(d_top, h_top, sizeof(int32_t) * (size_t)cand, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_stage_rest_box, dim3(std::min((st.n + 255) / 256, 1024)), dim3(256), 0, stream, st.d_tris, st.n, d_top, cand, st.d_misc + 8);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    int ord[6];
+    if ((e = hipMemcpyAsync(ord, st.d_misc + 8, sizeof ord, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    for (int j = 0; j < 6; ++j) {
+        const int i = ord[j] >= 0 ? ord[j] : ord[j] ^ 0x7fffffff;
+        std::memcpy(&box[j], &i, sizeof(float));
+    }
+    return hipSuccess;
+}
+
+// fills st.d_sel with the add-order indices of the triangles that are not on the (ascending) list
+hipError_t stage_select(const DeviceStage& st, const int32_t* h_flat, int nf, hipStream_t stream) {
+    hipError_t e;
+    int32_t* d_flat = reinterpret_cast<int32_t*>(st.d_misc + 16);
+    if (nf > 0 && (e = hipMemcpyAsync(d_flat, h_flat, sizeof(int32_t) * (size_t)nf, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    const int ns = st.n - nf;
+    hipLaunchKernelGGL(k_stage_select, dim3((ns + 255) / 256), dim3(256), 0, stream, ns, d_flat, nf, st.d_sel);
+    return hipGetLastError();
+}
+
+void stage_free(DeviceStage* st) {
+    if (st->base) (void)hipFree(st->base);
+    *st = DeviceStage();
 }
 
 }  // namespace ptamd
