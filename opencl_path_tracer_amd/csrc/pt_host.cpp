@@ -136,8 +136,9 @@ struct pt_context {
     int debug_repeat = 0; // pt_debug_closest_hit: extra timed launches
     int cost_binning = 1; // wavefront: separate ray queues for rays that touch a complex object's box
     int bvh_policy = 0;   // 0/1 host SAH with SAH leaf termination, 2 leaves of <= 4, 3 leaves of <= 8, 4 device LBVH, 5 the SAH tree built on the device
-    int sah_grain = 128;  // device SAH builder: ranges of at most this many triangles are finished by one wave each
+    int sah_grain = 256;  // device SAH builder: ranges of at most this many triangles are finished by one wave each
     int wide_on_device = 1;  // device-built trees: the 4-wide collapse runs on the device too (0: on the host)
+    int bvh_device = -1;     // SAH policies 0..3: build on the device (the same tree)?  -1: scenes of >= kDeviceBuildFrom triangles, 0 never, 1 always
 
     // ---- statistics
     std::vector<EventPair> events;
@@ -1749,10 +1750,12 @@ static int build_on_device(pt_context* ctx, bool* done) {
     const int threads = host_threads(ctx);
     clk.lap("big-triangle list");
     LbvhResult r;
-    const bool sah = ctx->bvh_policy == 5;
-    if (sah) {                                  // the host builder's tree (policy 0), node for node; the host builds what the device cannot
+    const bool sah = ctx->bvh_policy != 4;
+    if (sah) {                                  // the host builder's tree, node for node; the host builds what the device cannot
         bool unsupported = false;
-        PT_HIP(ctx, sah_device_build(st.d_tris, st.d_rank, n, d_sel, ns, 4, false, (float)ctx->sah_visit_cost * 0.1f, ctx->sah_grain, ctx->stream, &r, &unsupported));
+        const bool forced = ctx->bvh_policy == 2 || ctx->bvh_policy == 3;            // (as build_and_pack reads the policy)
+        PT_HIP(ctx, sah_device_build(st.d_tris, st.d_rank, n, d_sel, ns, ctx->bvh_policy == 3 ? 8 : 4, forced, (float)ctx->sah_visit_cost * 0.1f, ctx->sah_grain, ctx->stream, &r,
+                                     &unsupported));
         if (unsupported) return PT_OK;
         clk.lap("sah_device_build");
     } else {
@@ -1849,7 +1852,10 @@ int pt_upload_triangles(pt_context* ctx) {
     if (ctx->tri_shift != (int32_t)ctx->tris.size())
         return fail(ctx, PT_EINVAL, "triangles were added after the last end_Obj; close the object first (main.cpp:536)");
     const auto t0 = std::chrono::steady_clock::now();
-    if (ctx->bvh_policy >= 4) {
+    // Policies 0..3 name a TREE (binned SAH, leaf rule); where it is built does not change it: on the device (pt_sahdev.hip, the
+    // same nodes) for scenes big enough to repay the launches, on the host otherwise and for whatever the device hands back.
+    const bool on_device = ctx->has_device && (ctx->bvh_policy >= 4 || ctx->bvh_device == 1 || (ctx->bvh_device < 0 && (int64_t)ctx->tris.size() >= kDeviceBuildFrom));
+    if (on_device) {
         bool done = false;
         int rcd = build_on_device(ctx, &done);
         if (rcd != PT_OK) return rcd;
@@ -2324,6 +2330,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "waves_per_simd") {
         if (value != -1 && (value < 4 || value > 8)) return fail(ctx, PT_EINVAL, "waves_per_simd: -1 automatic (at most 7), 4..8 (kernels that read nodes from global memory)");
         ctx->waves_per_simd = (int)value;
+    } else if (k == "bvh_device") {
+        if (value < -1 || value > 1) return fail(ctx, PT_EINVAL, "bvh_device: -1 (by scene size), 0 (host) or 1 (device)");
+        ctx->bvh_device = (int)value;
     } else if (k == "wide_on_device") {
         if (value != 0 && value != 1) return fail(ctx, PT_EINVAL, "wide_on_device: 0 or 1");
         ctx->wide_on_device = (int)value;

@@ -742,19 +742,25 @@ def test_device_bvh_builder(api, oracle, cb_spec, cb_oracle_scene, which, ntris)
     check(sc, fr, "device bvh wavefront %s" % which)
 
 
-@pytest.mark.parametrize("which,ntris,grain", [("cornell", 0, 64), ("cornell", 0, 4096), ("mesh", 6000, 512), ("mesh", 100000, 512), ("mesh", 100000, 64),
-                                               ("mesh", 100000, 8192), ("mesh", 1000000, 512)])
-def test_device_sah_builder_same_tree(api, cb_spec, which, ntris, grain):
-    """bvh_policy 5: the host builder's binned-SAH tree built ON THE DEVICE (pt_sahdev.hip) -- the same nodes (boxes bit for
-    bit, references, order), the same packed triangles, the same depth as bvh_policy 0, whatever the grain that divides
-    the work between the level-synchronous top phase and the one-wave-per-range bottom phase."""
+@pytest.mark.parametrize("which,ntris,grain,policy", [("cornell", 0, 64, 0), ("cornell", 0, 4096, 0), ("mesh", 6000, 512, 0), ("mesh", 100000, 128, 0),
+                                                      ("mesh", 100000, 64, 0), ("mesh", 100000, 8192, 0), ("mesh", 1000000, 128, 0),
+                                                      ("mesh", 100000, 128, 2), ("mesh", 100000, 128, 3), ("cornell", 0, 128, 3)])
+def test_device_sah_builder_same_tree(api, cb_spec, which, ntris, grain, policy):
+    """The host builder's binned-SAH tree built ON THE DEVICE (pt_sahdev.hip; the default for scenes of 16k triangles or more,
+    `bvh_device` 1 / `bvh_policy` 5 for any): the same nodes (boxes bit for bit, references, order), the same packed triangles,
+    the same depth, the same 4-wide nodes (collapsed on the device too, pt_widedev.hip) as the host builder with the same leaf
+    policy, whatever the grain that divides the work between the level-synchronous top phase and the one-wave-per-range
+    bottom phase."""
     from opencl_path_tracer_amd import scenes
     spec = cb_spec if which == "cornell" else scenes.displaced_grid_mesh(ntris)
     ref = api.Scene(32, 32)
+    ref.set_option("bvh_device", 0)
+    ref.set_option("bvh_policy", policy)
     ref.load(spec)
     assert ref.stat("bvh_on_device") == 0
     dev = api.Scene(32, 32)
-    dev.set_option("bvh_policy", 5)
+    dev.set_option("bvh_policy", policy if policy else 5)       # (5: policy 0's tree, on the device whatever the scene size)
+    dev.set_option("bvh_device", 1)
     dev.set_option("sah_grain", grain)
     dev.load(spec)
     assert dev.stat("bvh_on_device") == 1

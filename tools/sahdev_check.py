@@ -14,6 +14,7 @@ for name, grain in cases:
     spec = scenes.cornell_box() if name == "cornell" else scenes.displaced_grid_mesh({"mesh6k": 6000, "mesh100k": 100000, "mesh1M": 1000000}[name])
     print("== %s grain %d" % (name, grain), flush=True)
     ref = api.Scene(32, 32)
+    ref.set_option("bvh_device", 0)
     ref.load(spec)
     ref.upload_Triangles()
     dev = api.Scene(32, 32)
