@@ -169,8 +169,14 @@ void* pt_device_rnds(pt_context* ctx);
 int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStream_t; NULL = default stream */
 /* options (key, value):
  *   "variant"      0 megakernel (default), 1 wavefront (stream-compacted, path state in HBM)
- *   "bvh_policy"   0 host SAH (default), 2 / 3 host SAH with leaves forced to <= 4 / <= 8 triangles, 4 device LBVH;
- *                  set before the triangles are uploaded
+ *   "bvh_policy"   WHICH tree: 0 binned SAH with SAH leaf termination (default), 2 / 3 the same with every subtree of <= 4 /
+ *                  <= 8 triangles forced into a leaf, 4 Morton order + PLOC merges (device only, a cheaper and worse tree),
+ *                  5 = 0 built on the device whatever the scene size; set before the triangles are uploaded
+ *   "bvh_device"   WHERE the SAH tree of policies 0..3 is built -- the result is the same, node for node: -1 (default) on the
+ *                  device for scenes of >= 16,384 triangles, 0 on the host, 1 on the device.  The host builds whatever the
+ *                  device hands back (non-finite triangles, ranges that need the median split)
+ *   "sah_grain"    device SAH builder: ranges of at most this many triangles are finished by one wave each (default 256; 8..65536)
+ *   "wide_on_device" device-built trees: 1 (default) the 4-wide collapse runs on the device too (the same nodes), 0 on the host
  *   "lds_scene"    2 (default) every workgroup stages BVH nodes in LDS: the whole tree when it fits (<= 64 KB,
  *                  <= 4096 triangles), otherwise its top if "treelet" asks for one (else the nodes are read through
  *                  L1/L2, see "wide_nodes"); 0 every node through L1/L2
