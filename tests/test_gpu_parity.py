@@ -782,6 +782,51 @@ def test_device_sah_builder_same_tree(api, cb_spec, which, ntris, grain, policy)
         assert same_bits(ref.read_colors(), dev.read_colors())
 
 
+def _soup_spec(n, seed, copies=0):
+    """Cornell walls + n random triangles of very mixed sizes in three objects (+ `copies` coincident copies of one
+    cube-spanning triangle: more equal centroids than a leaf holds, which only a median split can separate)."""
+    from opencl_path_tracer_amd import scenes
+    rng = np.random.RandomState(seed)
+    spec = scenes.SceneSpec(materials=list(scenes.BUILTIN_MATERIALS), name="soup_%d" % n)
+    spec.objects.append(scenes.cornell_walls())
+    for k in range(3):
+        m = n // 3
+        c = (rng.uniform(-1, 1, (m, 1, 3)) * [450, 400, 700] + [500, 450, 100]).astype(np.float32)
+        size = np.exp(rng.uniform(np.log(0.5), np.log(60.0), (m, 1, 1)))
+        v = (c + rng.normal(size=(m, 3, 3)) * size).astype(np.float32)
+        if copies and k == 1:            # different triangles spanning the same cube: equal boxes, equal box centres
+            corners = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], dtype=np.float32)
+            spans = [t for t in __import__("itertools").combinations(range(8), 3)
+                     if all(set(corners[list(t)][:, a]) == {0.0, 1.0} for a in range(3))]
+            at = v[100, 0].copy()
+            for j in range(copies):
+                v[100 + j] = at + 7.0 * corners[list(spans[j])]
+        spec.objects.append((v, np.full(m, [scenes.WHITE_DIFFUSE, scenes.CHROMIUM, scenes.GLASS][k], dtype=np.uint16)))
+    return spec
+
+
+def test_device_sah_builder_soup_and_hand_back(api):
+    """The device SAH builder on a triangle soup (sizes over two decades, three objects): the host's tree again.  With
+    nine coincident triangles in it the host needs its median split, which the device does not reproduce: the build is
+    handed back (bvh_on_device 0) and the scene is the host's in every respect."""
+    for copies in (0, 9):
+        spec = _soup_spec(60000, 5, copies)
+        ref = api.Scene(48, 48)
+        ref.set_option("bvh_device", 0)
+        ref.load(spec)
+        dev = api.Scene(48, 48)
+        dev.set_option("bvh_device", 1)
+        dev.load(spec)
+        assert dev.stat("bvh_on_device") == (0 if copies else 1)
+        a, b = ref.debug_bvh(), dev.debug_bvh()
+        assert np.array_equal(a[3], b[3]) and same_bits(a[0], b[0]) and same_bits(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert ref.debug_wide_nodes().tobytes() == dev.debug_wide_nodes().tobytes()
+        ref.iterations = dev.iterations = 4
+        ref.render(2)
+        dev.render(2)
+        assert same_bits(ref.read_colors(), dev.read_colors())
+
+
 def test_closest_hit_unit_level_mesh(api, oracle):
     """Same unit-level check on the 100k-triangle mesh scene with both builders: device result ==
     exhaustive search == the reference's own traversal on 3,000 random rays."""
