@@ -414,3 +414,208 @@ def test_running_mean_over_several_launches(api, variant):
     two.render(11)
     exp16 = 2.0 * LAMP_E[None, :] * F0[None, :] * np.mean(vals[:16], axis=0)[:, None]
     assert np.allclose(two.read_colors()[:, :3].astype(np.float64), exp16, rtol=2e-5, atol=0)
+
+
+# ---- round 3, second batch: oblique Fresnel, Snell's law through a wedge, the camera under yaw / pitch / shift -------------
+
+def rot_y(v, deg):                              # main.cpp:55-62
+    b = np.float64(np.float32(deg) / np.float32(180.0) * np.float32(3.141593))
+    return np.array([v[0] * np.cos(b) + v[2] * np.sin(b), v[1], -v[0] * np.sin(b) + v[2] * np.cos(b)])
+
+
+def rot_x(v, deg):                              # main.cpp:63-70
+    g = np.float64(np.float32(deg) / np.float32(180.0) * np.float32(3.141593))
+    return np.array([v[0], v[1] * np.cos(g) - v[2] * np.sin(g), v[1] * np.sin(g) + v[2] * np.cos(g)])
+
+
+def camera_general(W, H, fov, yaw, pitch, shift, ids, r1, r2):
+    """eye and unit ray directions for any view (main.cpp:311-347, prog.cl:82-92)."""
+    ahead_len = (W / 2.0) / np.tan(np.float32(fov / 2.0 / 180.0 * np.float32(3.141593)).astype(np.float64))
+    up = rot_y(rot_x(np.array([0.0, 1.0, 0.0]), pitch), yaw) * (H / 2.0)
+    right = rot_y(rot_x(np.array([1.0, 0.0, 0.0]), pitch), yaw) * (W / 2.0)
+    ahead = rot_y(rot_x(np.array([0.0, 0.0, 1.0]), pitch), yaw) * ahead_len
+    eye = np.array([500.0 + shift[0], 500.0 + shift[1], float(np.float32(EYE_Z)) + shift[2]])
+    x = (ids % W) + r1
+    y = (ids // W) + r2
+    p = ahead[None, :] + right[None, :] * (2.0 * x / W - 1.0)[:, None] + up[None, :] * (2.0 * y / H - 1.0)[:, None]
+    return eye, p / np.linalg.norm(p, axis=1)[:, None]
+
+
+def fresnel(F0, c):                             # prog.cl:219-222
+    return F0 + (1.0 - F0) * (1.0 - c) ** 5
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_mirror_at_seventy_degrees(api, variant):
+    """Camera -> chromium mirror tilted so that the view axis meets it at 70 degrees -> small emitter square on to the
+    reflected beam, iterations = 2.  The Fresnel factor is far from F0 there: F = F0 + (1 - F0)(1 - |N.D|)^5 with
+    (1 - cos 70)^5 = 0.123 (prog.cl:219-222); the reflected direction is D - 2 (D.N) N (prog.cl:223-227) and the emitter
+    weighs it with |D'.N_e| (prog.cl:358-362).  Every sample is 2 E F(|N.D|) |D'.N_e|, 4 draws."""
+    from opencl_path_tracer_amd import scenes
+    W = H = 32
+    S, fov = 24, 2.0
+    al = np.deg2rad(70.0)
+    n = np.array([-np.sin(al), 0.0, -np.cos(al)])
+    hit0 = np.array([500.0, 500.0, 1000.0])
+    r0 = np.array([-np.sin(2 * al), 0.0, -np.cos(2 * al)])
+    mirror = tri_around(hit0, (np.cos(al), 0.0, -np.sin(al)), (0, 1, 0), 250.0)
+    lamp = tri_around(hit0 + 3000.0 * r0, (r0[2], 0.0, -r0[0]), (0, 1, 0), 400.0)
+    sc = build(api, W, H, fov, [(mirror, scenes.CHROMIUM), (lamp, scenes.LAMP)])
+    sc.set_option("variant", variant)
+    sc.iterations = 2
+    sc.render(S)
+    got = sc.read_colors()[:, :3].astype(np.float64)
+    n_, k_ = np.array([3.10, 3.05, 2.05], np.float32), np.array([3.3, 3.3, 2.9], np.float32)     # main.cpp:760
+    F0 = ((k_ * k_ + (n_ - 1) * (n_ - 1)) / (k_ * k_ + (n_ + 1) * (n_ + 1))).astype(np.float64)  # main.cpp:105-109
+    state = seeds(W * H)
+    ids = np.arange(W * H)
+    acc = np.zeros((W * H, 3))
+    for s in range(S):
+        state, r1 = draw32(state)
+        state, r2 = draw32(state)
+        D = camera_dir(W, H, fov, ids, r1, r2)
+        dn = D @ n
+        Dr = D - 2.0 * dn[:, None] * n[None, :]
+        Dr /= np.linalg.norm(Dr, axis=1)[:, None]
+        acc += 2.0 * LAMP_E[None, :] * fresnel(F0[None, :], np.abs(dn)[:, None]) * np.abs(Dr @ r0)[:, None]
+        state, _ = draw32(state)
+        state, _ = draw32(state)
+    exp = acc / S
+    assert (fresnel(F0, np.cos(al)) / F0).min() > 1.03           # the angle term is really exercised
+    assert np.allclose(got, exp, rtol=5e-5, atol=0), float(np.abs(got / exp - 1).max())
+    assert np.array_equal(sc.read_rnds().astype(np.int64), state)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_snell_refraction_through_a_wedge(api, variant):
+    """Camera -> glass wedge: entry face square on to the view axis, exit face tilted by 30 degrees -> an emitter that the
+    deviated beam meets at ~55 degrees, so its cosine moves with the exit DIRECTION to first order.  iterations = 3.
+    prog.cl:228-245: entering, n = 1.5; leaving, `in` is set and n -> 1/1.5: disc = 1 - (1 - cos^2 30) 1.5^2 = 0.4375 > 0,
+    D' = normalize(D / n + N (cos / n - sqrt(disc))): sin(out) = 1.5 sin 30, the beam turns by 18.6 degrees.  A kernel
+    without the 1/n flip would turn it the other way (disc = 0.89).  Glass has equal channels, so (1 - F) / (1 - prob) = 1
+    and factor_R stays 1 (prog.cl:349-353).  Per sample, decided by the LCG stream against prob = mean F(|N.D|):
+      entry face reflects                 -> void: 0,                  draws 2 + 1
+      enters, exit face refracts          -> emitter: 2 E |D'.N_e|,    draws 2 + 1 + 1 + 2
+      enters, exit face reflects          -> entry face from inside, out of iterations: 0,   draws 2 + 1 + 1 + 1"""
+    from opencl_path_tracer_amd import scenes
+    W = H = 32
+    S, fov = 64, 2.0
+    g = np.deg2rad(30.0)
+    n1 = np.array([0.0, 0.0, -1.0])                       # entry face z = 1000, towards the camera
+    n2 = np.array([np.sin(g), 0.0, np.cos(g)])            # exit face through (500, 500, 1100), away from the camera
+    p2 = np.array([500.0, 500.0, 1100.0])
+    face1 = tri_around((500.0, 500.0, 1000.0), (1, 0, 0), (0, 1, 0), 600.0)
+    face2 = tri_around(p2, (np.cos(g), 0.0, -np.sin(g)), (0, 1, 0), 600.0)
+    # central exit direction: by hand, sin(out) = 1.5 sin(g) measured from n2
+    out = np.arcsin(1.5 * np.sin(g))
+    e0 = np.array([np.sin(g - out), 0.0, np.cos(g - out)])          # n2 turned by -out about y... (checked below against the formula)
+    tilt = np.deg2rad(55.0)
+    ne = np.array([e0[0] * np.cos(tilt) + e0[2] * np.sin(tilt), 0.0, -e0[0] * np.sin(tilt) + e0[2] * np.cos(tilt)])
+    lamp = tri_around(p2 + 3000.0 * e0, (ne[2], 0.0, -ne[0]), (0, 1, 0), 1500.0)
+    sc = build(api, W, H, fov, [(face1, scenes.GLASS), (face2, scenes.GLASS), (lamp, scenes.SUN)])
+    sc.set_option("variant", variant)
+    sc.iterations = 3
+    sc.render(S)
+    got = sc.read_colors()[:, :3].astype(np.float64)
+    F0 = float(np.float32(0.25) / np.float32(6.25))
+
+    def refract(D, N, n):                                 # prog.cl:232-242 (N opposes D)
+        cosa = -(D * N[None, :]).sum(axis=1)
+        disc = 1.0 - (1.0 - cosa * cosa) / n / n
+        assert (disc > 0).all()
+        R = D / n + N[None, :] * (cosa / n - np.sqrt(disc))[:, None]
+        return R / np.linalg.norm(R, axis=1)[:, None], cosa
+
+    state = seeds(W * H)
+    ids = np.arange(W * H)
+    acc = np.zeros((W * H, 3))
+    safe = np.ones(W * H, bool)
+    n_out = n_back = n_refl = 0
+    for s in range(S):
+        state, r1 = draw32(state)
+        state, r2 = draw32(state)
+        D = camera_dir(W, H, fov, ids, r1, r2)
+        D1, c1 = refract(D, n1, 1.5)
+        D2, c2 = refract(D1, -n2, 1.0 / 1.5)
+        if s == 0:
+            assert np.abs(D2 - e0[None, :]).max() < 0.03             # the hand-derived deviation
+        p1, p2_ = fresnel(F0, c1), fresnel(F0, c2)
+        sA, rA = draw32(state)                                       # entry face
+        safe &= np.abs(sA - p1 * 2147483648.0) > 64
+        refl = rA <= p1
+        sB, rB = draw32(sA)                                          # exit face
+        safe &= refl | (np.abs(sB - p2_ * 2147483648.0) > 64)
+        leaves = ~refl & (rB > p2_)
+        back = ~refl & ~leaves
+        acc += np.where(leaves[:, None], 2.0 * SUN_E[None, :] * np.abs(D2 @ ne)[:, None], 0.0)
+        s5, _ = draw32(sB)
+        s6, _ = draw32(s5)
+        state = np.where(refl, sA, np.where(leaves, s6, s5))
+        n_out += int(leaves.sum()); n_back += int(back.sum()); n_refl += int(refl.sum())
+    exp = acc / S
+    assert n_out > 55000 and n_back > 1500 and n_refl > 1500 and safe.sum() > W * H - 4
+    ok = safe
+    assert np.allclose(got[ok], exp[ok], rtol=1e-4, atol=1e-3), float(np.abs(got[ok] - exp[ok]).max())
+    assert np.array_equal(sc.read_rnds().astype(np.int64)[ok], state[ok])
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_camera_under_yaw_pitch_and_shift(api, variant):
+    """Which pixels see a small emitter, and under which cosine, for a view with yaw, pitch and a shifted eye
+    (main.cpp:311-347: rotate_x then rotate_y of up / right / ahead, eye = (500, 500, -1299.04) + shift; prog.cl:82-92).
+    Preview mode (iterations = 1, prog.cl:323-325, 358-362): a sample that hits the emitter reads E + 2 E |D.N_e| and draws
+    4 numbers, one that misses reads 0 and draws 2.  The expected hit set comes from a float64 ray / triangle test here;
+    pixels with a sample within 1e-3 (barycentric) of an edge are left out."""
+    from opencl_path_tracer_amd import scenes
+    W, H = 48, 40
+    S, fov, yaw, pitch, shift = 16, 60.0, 25.0, -12.0, (40.0, -30.0, 100.0)
+    ids = np.arange(W * H)
+    eye, Dc = camera_general(W, H, fov, yaw, pitch, shift, np.array([W * H // 2 + W // 2]), np.array([0.5]), np.array([0.5]))
+    centre = eye + 1500.0 * Dc[0]
+    tri = np.array([centre + np.array([-520.0, -300.0, 180.0]), centre + np.array([600.0, -240.0, -280.0]), centre + np.array([40.0, 660.0, 120.0])])
+    tri32 = tri.astype(np.float32)
+    sc = api.Scene(W, H)
+    for m in scenes.BUILTIN_MATERIALS:
+        sc.add_Material(*m)
+    sc.add_Triangles(api.triangles_from_vertices(tri32[None, :, :], np.full(1, scenes.LAMP, dtype=np.uint16)))
+    sc.end_Obj()
+    sc.upload_Triangles()
+    sc.upload_Materials()
+    sc.set_view(fov, yaw, pitch, shift)
+    sc.set_option("variant", variant)
+    sc.iterations = 1
+    sc.render(S)
+    got = sc.read_colors()[:, :3].astype(np.float64)
+    a, b, c = (tri32[k].astype(np.float64) for k in range(3))
+    nrm = np.cross(b - a, c - a)
+    nrm /= np.linalg.norm(nrm)
+    state = seeds(W * H)
+    acc = np.zeros((W * H, 3))
+    safe = np.ones(W * H, bool)
+    hits = 0
+    for s in range(S):
+        state, r1 = draw32(state)
+        state, r2 = draw32(state)
+        eye, D = camera_general(W, H, fov, yaw, pitch, shift, ids, r1, r2)
+        t = ((a - eye) @ nrm) / (D @ nrm)
+        P = eye[None, :] + D * t[:, None]
+        # barycentric coordinates of P
+        v0, v1, v2 = b - a, c - a, P - a[None, :]
+        d00, d01, d11 = v0 @ v0, v0 @ v1, v1 @ v1
+        d20, d21 = v2 @ v0, v2 @ v1
+        den = d00 * d11 - d01 * d01
+        bv = (d11 * d20 - d01 * d21) / den
+        bw = (d00 * d21 - d01 * d20) / den
+        bu = 1.0 - bv - bw
+        m = np.minimum(np.minimum(bu, bv), bw)
+        hit = (m > 0) & (t > 0)
+        safe &= np.abs(m) > 1e-3
+        acc += np.where(hit[:, None], LAMP_E[None, :] * (1.0 + 2.0 * np.abs(D @ nrm))[:, None], 0.0)
+        s3, _ = draw32(state)
+        s4, _ = draw32(s3)
+        state = np.where(hit, s4, state)
+        hits += int(hit.sum())
+    exp = acc / S
+    assert 0.1 < hits / (W * H * S) < 0.6 and safe.sum() > 0.8 * W * H
+    assert np.allclose(got[safe], exp[safe], rtol=2e-5, atol=1e-5), float(np.abs(got[safe] - exp[safe]).max())
+    assert np.array_equal(sc.read_rnds().astype(np.int64)[safe], state[safe])
