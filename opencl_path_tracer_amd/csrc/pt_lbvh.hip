@@ -473,8 +473,8 @@ hipError_t lbvh_build(const pt_triangle* d_tris, const int32_t* d_rank, int n_al
     LB_HIP(hipMalloc((void**)&d_oidx, sizeof(int) * (size_t)ni));
     LB_HIP(hipMalloc((void**)&d_misc, sizeof(int) * 8));
     // misc: [0..2] centroid min (ordered ints), [3..5] centroid max, [6] max depth
+    int init[8];                                   // (function scope: alive until the copy has run)
     {
-        int init[8];
         union { float f; int i; } pinf, ninf;
         pinf.f = INFINITY;
         ninf.f = -INFINITY;

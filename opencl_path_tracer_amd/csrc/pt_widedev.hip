@@ -344,13 +344,11 @@ hipError_t wide_device_build(const float4* d_bvh2, int n_nodes, hipStream_t stre
     int* d_sc = reinterpret_cast<int*>(d_all + o_sc);
     int* d_misc = reinterpret_cast<int*>(d_all + o_misc);          // [0] next level's count, [1] head, [2] max pending, [3] failed
     void* d_temp = d_all + o_temp;
-    {
-        const int init[8] = {0, 0x7fffffff, 0, 0, 0, 0, 0, 0};
-        WD_HIP(hipMemcpyAsync(d_misc, init, sizeof init, hipMemcpyHostToDevice, stream));
-        const int zero = 0;
-        WD_HIP(hipMemcpyAsync(w.src, &zero, sizeof(int), hipMemcpyHostToDevice, stream));       // node 0 = BVH2 root
-        WD_HIP(hipMemcpyAsync(w.pend, &zero, sizeof(int), hipMemcpyHostToDevice, stream));
-    }
+    const int init[8] = {0, 0x7fffffff, 0, 0, 0, 0, 0, 0};       // (function scope: alive until the copies have run)
+    const int zero = 0;
+    WD_HIP(hipMemcpyAsync(d_misc, init, sizeof init, hipMemcpyHostToDevice, stream));
+    WD_HIP(hipMemcpyAsync(w.src, &zero, sizeof(int), hipMemcpyHostToDevice, stream));           // node 0 = BVH2 root
+    WD_HIP(hipMemcpyAsync(w.pend, &zero, sizeof(int), hipMemcpyHostToDevice, stream));
     // 1. expansion
     std::vector<int> level_begin;
     int begin = 0, count = 1;
