@@ -446,3 +446,31 @@ def test_analytic_dielectric_split(oracle):
     cos_e = np.abs(D1[:, 1])
     want = np.array([1.0, 2.0, 3.0])[None, :] * 2.0 * (fR * cos_e)[:, None]
     assert np.allclose(cols[up], want[up], rtol=5e-6)
+
+
+@pytest.mark.parametrize("which", ["walls", "cornell"])
+def test_oracle_against_the_float64_replay_model(oracle, api, which):
+    """The oracle itself against the independent float64 numpy model of the whole hot path that the GPU tests use
+    (tests/test_gpu_closed_form.py::replay_model, written from prog.cl's text: exact triangle test over all triangles, closest
+    hit, diffuse / mirror / glass / emitter, the LCG stream per pixel): the Cornell walls at five bounces and BASELINE's Cornell
+    box at eight.  Same criteria as on the GPU: colours within 2e-4 and the SAME final LCG state in every pixel whose
+    decisions were clear of float32 / float64 ties -- the state encodes the sequence of materials each path met."""
+    import importlib.util
+    import os
+    from opencl_path_tracer_amd import scenes
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec_ = importlib.util.spec_from_file_location("closed_form_model", os.path.join(here, "test_gpu_closed_form.py"))
+    cf = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(cf)
+    m = cf.replay_model(api, which)
+    spec = scenes.SceneSpec(materials=list(scenes.BUILTIN_MATERIALS), name=which)
+    spec.objects = list(m["objects"])
+    osc = oracle.load_scene(spec)
+    cam = oracle.make_camera(spec.fov, spec.yaw, spec.pitch, spec.shift, m["W"], m["H"])
+    fr = oracle.OracleFrame(m["W"], m["H"])
+    fr.render(osc, cam, m["ITER"], 0, m["S"], mode=0, nthreads=8)
+    got = fr.colors()[:, :3].astype(np.float64)
+    safe = m["safe"]
+    assert safe.sum() > 0.95 * safe.size
+    assert np.allclose(got[safe], m["exp"][safe], rtol=2e-4, atol=1e-4), float(np.abs(got[safe] - m["exp"][safe]).max())
+    assert np.array_equal(fr.rnds().astype(np.int64)[safe], m["state"][safe])
