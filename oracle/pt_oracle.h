@@ -15,8 +15,12 @@
  *   library and a CPU OpenCL device -- none exist here).  What IS pinned, by
  *   tests/test_oracle_*.py: the seed sequence against libstdc++'s std::minstd_rand0
  *   (the very generator main.cpp:45 uses), the C++-standard known answers for both
- *   LCGs, the OpenCL struct layouts, analytic radiance cases read off prog.cl, and
- *   internal consistency (heap-array traversal == pointer traversal == brute force).
+ *   LCGs, the OpenCL struct layouts, analytic radiance cases read off prog.cl,
+ *   internal consistency (heap-array traversal == pointer traversal == brute force), and
+ *   -- round 3 -- an independent float64 numpy model of the whole path, replayed per pixel
+ *   from the LCG stream on the Cornell box at eight bounces (tests/test_gpu_closed_form.py
+ *   replay_model): same colours within 2e-4 and the same final LCG state in every pixel
+ *   clear of float32 / float64 ties.  A second reading of prog.cl, not a run of it.
  *
  * Arithmetic contract ("the spec").  OpenCL C leaves the
  * precision of '/', sqrt, sin, cos, pow and the placement of fused multiply-adds to
