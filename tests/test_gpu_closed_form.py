@@ -631,9 +631,15 @@ def replay_model(api, which):
         return _replayed[which]
     from opencl_path_tracer_amd import scenes
     W, H, fov = 32, 24, 60.0
-    S, ITER = (16, 5) if which == "walls" else (8, 8)
+    S, ITER = (8, 8) if which == "cornell" else (16, 5)
     if which == "walls":
         objects = [scenes.cornell_walls()]
+    elif which == "glossy":                                            # the walls again, floor and far wall with a specular lobe (ks != 0)
+        v, mt = scenes.cornell_walls()
+        mt = mt.copy()
+        mt[2:4] = scenes.BLACK_SPECULAR                                  # far wall (main.cpp:759: kd .05, ks .3, shininess 200)
+        mt[10:12] = scenes.PURPLE_SPECULAR                               # floor (main.cpp:758: kd (.3, 0, 0), ks .3, shininess 200)
+        objects = [(v, mt)]
     else:
         objects = scenes.cornell_box().objects
     recs = np.concatenate([api.triangles_from_vertices(v, m) for v, m in objects])
@@ -644,6 +650,8 @@ def replay_model(api, which):
     f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
     mats = scenes.BUILTIN_MATERIALS
     kd = f32([mats[m][0] for m in mati])
+    ks = f32([mats[m][1] for m in mati])
+    shin = f32([mats[m][5] for m in mati])
     em = f32([mats[m][2] for m in mati])
     typ = np.array([mats[m][6] for m in mati])
     nN, nK = f32([mats[m][3] for m in mati]), f32([mats[m][4] for m in mati])
@@ -656,7 +664,7 @@ def replay_model(api, which):
     safe = np.ones(n, bool)
     eye = np.array([500.0, 500.0, float(np.float32(EYE_Z))])
     bounces = np.zeros(ITER + 1, dtype=np.int64)
-    seen = {0: 0, 1: 0, 2: 0, 3: 0, "refr": 0, "tir": 0}
+    seen = {0: 0, 1: 0, 2: 0, 3: 0, "refr": 0, "tir": 0, "lobe": 0.0}
     e1v, e2v, e3v = r2v - r1v, r3v - r2v, r1v - r3v
     elen = [np.linalg.norm(e, axis=1) for e in (e1v, e2v, e3v)]
     cen = (r1v + r2v + r3v) / 3.0                                        # a sphere around each triangle (a hit point lies inside it)
@@ -750,7 +758,13 @@ def replay_model(api, which):
             color += np.where((ty == 3)[:, None], em[k] * (fL + fB) * fS * fR * np.maximum(0.0, cosa)[:, None], 0.0)
             c = np.maximum(0.0, (D2 * Nn).sum(axis=1))
             fL = np.where((ty == 0)[:, None], fL * kd[k] * c[:, None], fL)
-            fB = np.where((ty == 0)[:, None], 0.0, fB)                   # ks = 0 for every type-0 material of these scenes
+            view = eye[None, :] - hp                                     # prog.cl:78-80, 335-338: halfway vector to the CAMERA EYE
+            view /= np.linalg.norm(view, axis=1)[:, None]
+            Hv = view + D2
+            Hv /= np.linalg.norm(Hv, axis=1)[:, None]
+            lobe_pow = np.maximum(0.0, (Nn * Hv).sum(axis=1)) ** shin[k]
+            fB = np.where((ty == 0)[:, None], fB * ks[k] * lobe_pow[:, None], fB)
+            seen["lobe"] += float((((ty == 0)[:, None] * fB).sum()))
             # mirror and glass
             F = fresnel(F0[k], np.abs(cosa)[:, None])
             Dm = D + Nn * (2.0 * cosa)[:, None]                          # D - N (N.D) 2
@@ -777,14 +791,16 @@ def replay_model(api, which):
     return _replayed[which]
 
 
-@pytest.mark.parametrize("variant,which", [(0, "walls"), (1, "walls"), (0, "cornell"), (1, "cornell")])
+@pytest.mark.parametrize("variant,which", [(0, "walls"), (1, "walls"), (0, "glossy"), (1, "glossy"), (0, "cornell"), (1, "cornell")])
 def test_paths_replayed_from_the_lcg_stream(api, variant, which):
     """An independent float64 model of the WHOLE hot path, written from prog.cl's text, against the GPU -- no oracle.
     `walls`: the Cornell walls alone (12 triangles: five diffuse walls and the lamp, open towards the camera), five bounces.
+    `glossy`: the same with a specular lobe on the floor and the far wall (ks = .3, shininess 200): factor_B stays alive.
     `cornell`: BASELINE's scene (+ the chromium and the glass sphere, 1,932 triangles), eight bounces.  Every path of every
     pixel is replayed: the camera ray, the exact triangle test and the closest hit over ALL triangles (prog.cl:94-122), the flip
     of N against the ray (326-328), diffuse: the cosine-sampled continuation about the orthonormal base of 186-218 from two LCG
-    draws, factor_L *= kd max(0, N.D'), factor_B *= ks pow(.) (= 0 for these walls; 329-340); mirror: D - 2 (D.N) N and
+    draws, factor_L *= kd max(0, N.D'), factor_B *= ks pow(max(0, N.H), shininess) with H the halfway vector to the camera
+    eye (329-340); mirror: D - 2 (D.N) N and
     factor_S *= Fresnel (219-227, 341-345); glass: one draw, n or 1/n by the `in` flag, disc, the refracted direction or the
     mirror branch, factor_R *= (1-F)/(1-prob) or F/prob (228-245, 346-357); emitter: E (factor_L + factor_B) factor_S
     factor_R max(0, -D.N) with the OLD direction (358-362); a miss ends the path (367-376).  Multi-bounce products, the order
@@ -814,5 +830,8 @@ def test_paths_replayed_from_the_lcg_stream(api, variant, which):
     assert safe.sum() > (0.85 if which == "walls" else 0.6) * n, safe.sum()
     lit = exp[safe].sum(axis=1) > 0
     assert lit.sum() > 0.3 * safe.sum()                                     # (the lamp is small: many paths never see it)
-    assert np.allclose(got[safe], exp[safe], rtol=2e-4, atol=1e-4), float(np.abs(got[safe] - exp[safe]).max())
+    if which == "glossy":
+        assert seen["lobe"] > 1.0, seen                                     # the lobe factor really contributes
+    rtol = 2e-3 if which == "glossy" else 2e-4                              # pow(., 200) multiplies the float32 error of its argument by 200
+    assert np.allclose(got[safe], exp[safe], rtol=rtol, atol=1e-4), float(np.abs(got[safe] - exp[safe]).max())
     assert np.array_equal(sc.read_rnds().astype(np.int64)[safe], state[safe])
