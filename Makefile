@@ -3,7 +3,10 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 PKG     := opencl_path_tracer_amd
 CSRC    := $(PKG)/csrc
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-slp-vectorize -Iinclude -I$(CSRC) -Wall -Wno-unused-result
+# -amdgpu-sdwa-peephole=0: an SDWA v_cndmask_b32 can only take its mask from VCC, so the compiler copies the SGPR mask there
+# (s_mov_b64 vcc, ...) -- and a VCC-masked VOP2 / SDWA select whose VCC was not just written by a VALU compare costs 21 clocks
+# instead of 4 on gfx950 (tools/micro/exec_ops.hip).  Two of them sat in the node loop of k_render: +2.7 % on the Cornell box.
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sdwa-peephole=0 -Iinclude -I$(CSRC) -Wall -Wno-unused-result
 
 all: $(PKG)/libptamd.so oracle tests/cpp/dropin check-isa
 

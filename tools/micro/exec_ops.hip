@@ -43,6 +43,15 @@
 #define OP_SQRT(i) "v_sqrt_f32 %" #i ", %" #i "\n"
 #define OP_BITOP(i) "v_bitop3_b32 %" #i ", %" #i ", %8, %9 bitop3:0xcf\n"
 #define OP_CVT(i) "v_cvt_f32_i32 %" #i ", %" #i "\n"
+#define OP_MAD64(i) "v_mad_u64_u32 v[20:21], s[10:11], %" #i ", %8, v[20:21]\n"
+#define OP_CNDV(i) "v_cndmask_b32 %" #i ", %8, %9, vcc\n"
+#define OP_CND64V(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %9, vcc\n"
+#define OP_CNDSDWA(i) "v_cndmask_b32_sdwa %" #i ", %" #i ", %9, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+#define OP_CMPCND(i) "v_cmp_lt_f32 vcc, %" #i ", %9\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define OP_CMPGAP(i) "v_cmp_lt_f32 vcc, %" #i ", %9\nv_add_f32 v20, v20, %9\nv_add_f32 v21, v21, %9\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define OP_SMOVCND(i) "s_mov_b64 vcc, s[10:11]\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define OP_CMPCND2(i) "v_cmp_lt_f32 vcc, %" #i ", %9\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\nv_cndmask_b32 v20, v20, %8, vcc\n"
+#define OP_CMPCND64(i) "v_cmp_lt_f32_e64 s[10:11], %" #i ", %9\nv_cndmask_b32_e64 %" #i ", %" #i ", %8, s[10:11]\n"
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(unsigned long long mask, int iters, float* out) {
@@ -87,6 +96,15 @@ __global__ void __launch_bounds__(256) k(unsigned long long mask, int iters, flo
                 if (OP == 31) CHAIN8(OP_SQRT);
                 if (OP == 32) CHAIN8(OP_BITOP);
                 if (OP == 33) CHAIN8(OP_CVT);
+                if (OP == 34) CHAIN8(OP_MAD64);
+                if (OP == 35) CHAIN8(OP_CNDV);
+                if (OP == 36) CHAIN8(OP_CND64V);
+                if (OP == 37) CHAIN8(OP_CNDSDWA);
+                if (OP == 38) CHAIN8(OP_CMPCND);
+                if (OP == 39) CHAIN8(OP_CMPCND64);
+                if (OP == 40) CHAIN8(OP_CMPGAP);
+                if (OP == 41) CHAIN8(OP_SMOVCND);
+                if (OP == 42) CHAIN8(OP_CMPCND2);
             }
         }
     }
@@ -125,5 +143,8 @@ int main() {
     run<19>("v_med3_f32", o); run<20>("v_xor_b32", o); run<21>("v_fmac_f32", o); run<22>("v_fma sgpr op", o); run<23>("v_mul literal", o);
     run<24>("v_min_f32", o); run<25>("v_sub_u32", o); run<26>("v_lshrrev_b32", o); run<27>("v_pk_fma_f32", o); run<28>("v_pk_mul_f32", o);
     run<29>("v_fma_f64", o); run<30>("v_mul_f64", o); run<31>("v_sqrt_f32", o); run<32>("v_bitop3_b32", o); run<33>("v_cvt_f32_i32", o);
+    run<34>("v_mad_u64_u32", o); run<35>("cndmask indep", o);
+    run<36>("cndmask e64 vcc", o); run<37>("cndmask sdwa", o); run<38>("cmp+cnd vcc x2", o); run<39>("cmp+cnd sgpr x2", o);
+    run<40>("cmp,add,add,cnd", o); run<41>("s_mov vcc+cnd", o); run<42>("cmp,cnd,cnd", o);
     return 0;
 }
