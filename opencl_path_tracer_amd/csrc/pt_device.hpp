@@ -55,32 +55,40 @@ PT_DEV float max0(float c) { return c > 0.0f ? c : 0.0f; }
 // register pair at its point of use instead: two s_mov_b32 with literal operands, then v_fma_f64 reads the pair directly.
 // SK = false leaves the constants to the compiler: the 128-VGPR instance (whole tree in LDS) has room for them and is
 // 1 % faster that way (profiles/r03/d_*).
-template <bool SK>
-PT_DEV double KC(double c) {
-    if (SK) asm volatile("" : "+s"(c));
-    return c;
+template <bool SK, unsigned long long BITS>
+PT_DEV double kc_bits() {
+    if (SK) {
+        // (the literal is written by the asm itself: with the constant as an INPUT of an empty asm the compiler hoisted its
+        // materialisation out of the sample loop, ran out of scalar registers and kept it in VGPR lanes -- two v_readlane and two
+        // v_writelane per use, ~50 VALU instructions per cosine-sampled direction, profiles/r03/y_*)
+        unsigned lo, hi;
+        asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((unsigned)(BITS & 0xffffffffull)), "i"((unsigned)(BITS >> 32)));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+    }
+    return __builtin_bit_cast(double, BITS);
 }
+#define KC_(SK, x) kc_bits<SK, __builtin_bit_cast(unsigned long long, (double)(x))>()
 template <bool SK>
 PT_DEV void spec_sincos(float theta, float* s, float* c) {
     const double t = (double)theta;
-    const int q = (int)fmad_(t, KC<SK>(0.63661977236758138), 0.5);
+    const int q = (int)fmad_(t, KC_(SK, 0.63661977236758138), 0.5);
     const double qd = (double)q;
-    double r = fmad_(qd, KC<SK>(-1.5707963267948966), t);
-    r = fmad_(qd, KC<SK>(-6.123233995736766e-17), r);
+    double r = fmad_(qd, KC_(SK, -1.5707963267948966), t);
+    r = fmad_(qd, KC_(SK, -6.123233995736766e-17), r);
     const double z = r * r;
-    double ps = KC<SK>(1.6059043836821613e-10);
-    ps = fmad_(ps, z, KC<SK>(-2.505210838544172e-08));
-    ps = fmad_(ps, z, KC<SK>(2.7557319223985893e-06));
-    ps = fmad_(ps, z, KC<SK>(-0.0001984126984126984));
-    ps = fmad_(ps, z, KC<SK>(0.008333333333333333));
-    ps = fmad_(ps, z, KC<SK>(-0.16666666666666666));
+    double ps = KC_(SK, 1.6059043836821613e-10);
+    ps = fmad_(ps, z, KC_(SK, -2.505210838544172e-08));
+    ps = fmad_(ps, z, KC_(SK, 2.7557319223985893e-06));
+    ps = fmad_(ps, z, KC_(SK, -0.0001984126984126984));
+    ps = fmad_(ps, z, KC_(SK, 0.008333333333333333));
+    ps = fmad_(ps, z, KC_(SK, -0.16666666666666666));
     const double sr = fmad_(r * z, ps, r);
-    double pc = KC<SK>(-1.1470745597729725e-11);
-    pc = fmad_(pc, z, KC<SK>(2.08767569878681e-09));
-    pc = fmad_(pc, z, KC<SK>(-2.755731922398589e-07));
-    pc = fmad_(pc, z, KC<SK>(2.48015873015873e-05));
-    pc = fmad_(pc, z, KC<SK>(-0.001388888888888889));
-    pc = fmad_(pc, z, KC<SK>(0.041666666666666664));
+    double pc = KC_(SK, -1.1470745597729725e-11);
+    pc = fmad_(pc, z, KC_(SK, 2.08767569878681e-09));
+    pc = fmad_(pc, z, KC_(SK, -2.755731922398589e-07));
+    pc = fmad_(pc, z, KC_(SK, 2.48015873015873e-05));
+    pc = fmad_(pc, z, KC_(SK, -0.001388888888888889));
+    pc = fmad_(pc, z, KC_(SK, 0.041666666666666664));
     pc = fmad_(pc, z, -0.5);
     const double cr = fmad_(z, pc, 1.0);
     const int k = q & 3;
@@ -108,37 +116,37 @@ PT_DEV float spec_pow(float x, float y) {
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
     bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
     double m = __longlong_as_double((long long)bits);
-    if (m > KC<SK>(1.4142135623730951)) { m = m * 0.5; e += 1; }
+    if (m > KC_(SK, 1.4142135623730951)) { m = m * 0.5; e += 1; }
     const double f = m - 1.0;
     const double sdiv = f / (2.0 + f);
     const double z = sdiv * sdiv;
-    double p = KC<SK>(0.10526315789473684);
-    p = fmad_(p, z, KC<SK>(0.11764705882352941));
-    p = fmad_(p, z, KC<SK>(0.13333333333333333));
-    p = fmad_(p, z, KC<SK>(0.15384615384615385));
-    p = fmad_(p, z, KC<SK>(0.18181818181818182));
-    p = fmad_(p, z, KC<SK>(0.22222222222222221));
-    p = fmad_(p, z, KC<SK>(0.2857142857142857));
-    p = fmad_(p, z, KC<SK>(0.4));
-    p = fmad_(p, z, KC<SK>(0.66666666666666663));
+    double p = KC_(SK, 0.10526315789473684);
+    p = fmad_(p, z, KC_(SK, 0.11764705882352941));
+    p = fmad_(p, z, KC_(SK, 0.13333333333333333));
+    p = fmad_(p, z, KC_(SK, 0.15384615384615385));
+    p = fmad_(p, z, KC_(SK, 0.18181818181818182));
+    p = fmad_(p, z, KC_(SK, 0.22222222222222221));
+    p = fmad_(p, z, KC_(SK, 0.2857142857142857));
+    p = fmad_(p, z, KC_(SK, 0.4));
+    p = fmad_(p, z, KC_(SK, 0.66666666666666663));
     p = fmad_(p, z, 2.0);
     const double lnm = sdiv * p;
-    const double lg2 = fmad_(lnm, KC<SK>(1.4426950408889634), (double)e);
+    const double lg2 = fmad_(lnm, KC_(SK, 1.4426950408889634), (double)e);
     const double w = (double)y * lg2;
     if (!(w > -126.0)) return 0.0f;
     if (w >= 128.0) return __builtin_inff();
     const double nd = __builtin_floor(w + 0.5);
-    const double g = (w - nd) * KC<SK>(0.6931471805599453);
-    double q = KC<SK>(2.08767569878681e-09);
-    q = fmad_(q, g, KC<SK>(2.505210838544172e-08));
-    q = fmad_(q, g, KC<SK>(2.755731922398589e-07));
-    q = fmad_(q, g, KC<SK>(2.7557319223985893e-06));
-    q = fmad_(q, g, KC<SK>(2.48015873015873e-05));
-    q = fmad_(q, g, KC<SK>(0.0001984126984126984));
-    q = fmad_(q, g, KC<SK>(0.001388888888888889));
-    q = fmad_(q, g, KC<SK>(0.008333333333333333));
-    q = fmad_(q, g, KC<SK>(0.041666666666666664));
-    q = fmad_(q, g, KC<SK>(0.16666666666666666));
+    const double g = (w - nd) * KC_(SK, 0.6931471805599453);
+    double q = KC_(SK, 2.08767569878681e-09);
+    q = fmad_(q, g, KC_(SK, 2.505210838544172e-08));
+    q = fmad_(q, g, KC_(SK, 2.755731922398589e-07));
+    q = fmad_(q, g, KC_(SK, 2.7557319223985893e-06));
+    q = fmad_(q, g, KC_(SK, 2.48015873015873e-05));
+    q = fmad_(q, g, KC_(SK, 0.0001984126984126984));
+    q = fmad_(q, g, KC_(SK, 0.001388888888888889));
+    q = fmad_(q, g, KC_(SK, 0.008333333333333333));
+    q = fmad_(q, g, KC_(SK, 0.041666666666666664));
+    q = fmad_(q, g, KC_(SK, 0.16666666666666666));
     q = fmad_(q, g, 0.5);
     q = fmad_(q, g, 1.0);
     q = fmad_(q, g, 1.0);
