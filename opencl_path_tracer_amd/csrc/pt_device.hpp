@@ -68,6 +68,19 @@ PT_DEV double kc_bits() {
     return __builtin_bit_cast(double, BITS);
 }
 #define KC_(SK, x) kc_bits<SK, __builtin_bit_cast(unsigned long long, (double)(x))>()
+// a * b + K.  (Left to the compiler, a Horner step becomes v_fmac_f64 with the constant as the accumulator -- which has to be a VGPR
+// pair: two v_mov_b32 from the scalar pair per step, 46 per cosine-sampled direction.  v_fma_f64 takes the pair as it is.)
+template <bool SK, unsigned long long BITS>
+PT_DEV double fmad_k(double a, double b) {
+    if (SK) {
+        const double k = kc_bits<SK, BITS>();
+        double r;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+        return r;
+    }
+    return fmad_(a, b, __builtin_bit_cast(double, BITS));
+}
+#define FMADK(SK, a, b, x) fmad_k<SK, __builtin_bit_cast(unsigned long long, (double)(x))>(a, b)
 template <bool SK>
 PT_DEV void spec_sincos(float theta, float* s, float* c) {
     const double t = (double)theta;
@@ -77,18 +90,18 @@ PT_DEV void spec_sincos(float theta, float* s, float* c) {
     r = fmad_(qd, KC_(SK, -6.123233995736766e-17), r);
     const double z = r * r;
     double ps = KC_(SK, 1.6059043836821613e-10);
-    ps = fmad_(ps, z, KC_(SK, -2.505210838544172e-08));
-    ps = fmad_(ps, z, KC_(SK, 2.7557319223985893e-06));
-    ps = fmad_(ps, z, KC_(SK, -0.0001984126984126984));
-    ps = fmad_(ps, z, KC_(SK, 0.008333333333333333));
-    ps = fmad_(ps, z, KC_(SK, -0.16666666666666666));
+    ps = FMADK(SK, ps, z, -2.505210838544172e-08);
+    ps = FMADK(SK, ps, z, 2.7557319223985893e-06);
+    ps = FMADK(SK, ps, z, -0.0001984126984126984);
+    ps = FMADK(SK, ps, z, 0.008333333333333333);
+    ps = FMADK(SK, ps, z, -0.16666666666666666);
     const double sr = fmad_(r * z, ps, r);
     double pc = KC_(SK, -1.1470745597729725e-11);
-    pc = fmad_(pc, z, KC_(SK, 2.08767569878681e-09));
-    pc = fmad_(pc, z, KC_(SK, -2.755731922398589e-07));
-    pc = fmad_(pc, z, KC_(SK, 2.48015873015873e-05));
-    pc = fmad_(pc, z, KC_(SK, -0.001388888888888889));
-    pc = fmad_(pc, z, KC_(SK, 0.041666666666666664));
+    pc = FMADK(SK, pc, z, 2.08767569878681e-09);
+    pc = FMADK(SK, pc, z, -2.755731922398589e-07);
+    pc = FMADK(SK, pc, z, 2.48015873015873e-05);
+    pc = FMADK(SK, pc, z, -0.001388888888888889);
+    pc = FMADK(SK, pc, z, 0.041666666666666664);
     pc = fmad_(pc, z, -0.5);
     const double cr = fmad_(z, pc, 1.0);
     const int k = q & 3;
@@ -121,14 +134,14 @@ PT_DEV float spec_pow(float x, float y) {
     const double sdiv = f / (2.0 + f);
     const double z = sdiv * sdiv;
     double p = KC_(SK, 0.10526315789473684);
-    p = fmad_(p, z, KC_(SK, 0.11764705882352941));
-    p = fmad_(p, z, KC_(SK, 0.13333333333333333));
-    p = fmad_(p, z, KC_(SK, 0.15384615384615385));
-    p = fmad_(p, z, KC_(SK, 0.18181818181818182));
-    p = fmad_(p, z, KC_(SK, 0.22222222222222221));
-    p = fmad_(p, z, KC_(SK, 0.2857142857142857));
-    p = fmad_(p, z, KC_(SK, 0.4));
-    p = fmad_(p, z, KC_(SK, 0.66666666666666663));
+    p = FMADK(SK, p, z, 0.11764705882352941);
+    p = FMADK(SK, p, z, 0.13333333333333333);
+    p = FMADK(SK, p, z, 0.15384615384615385);
+    p = FMADK(SK, p, z, 0.18181818181818182);
+    p = FMADK(SK, p, z, 0.22222222222222221);
+    p = FMADK(SK, p, z, 0.2857142857142857);
+    p = FMADK(SK, p, z, 0.4);
+    p = FMADK(SK, p, z, 0.66666666666666663);
     p = fmad_(p, z, 2.0);
     const double lnm = sdiv * p;
     const double lg2 = fmad_(lnm, KC_(SK, 1.4426950408889634), (double)e);
@@ -138,15 +151,15 @@ PT_DEV float spec_pow(float x, float y) {
     const double nd = __builtin_floor(w + 0.5);
     const double g = (w - nd) * KC_(SK, 0.6931471805599453);
     double q = KC_(SK, 2.08767569878681e-09);
-    q = fmad_(q, g, KC_(SK, 2.505210838544172e-08));
-    q = fmad_(q, g, KC_(SK, 2.755731922398589e-07));
-    q = fmad_(q, g, KC_(SK, 2.7557319223985893e-06));
-    q = fmad_(q, g, KC_(SK, 2.48015873015873e-05));
-    q = fmad_(q, g, KC_(SK, 0.0001984126984126984));
-    q = fmad_(q, g, KC_(SK, 0.001388888888888889));
-    q = fmad_(q, g, KC_(SK, 0.008333333333333333));
-    q = fmad_(q, g, KC_(SK, 0.041666666666666664));
-    q = fmad_(q, g, KC_(SK, 0.16666666666666666));
+    q = FMADK(SK, q, g, 2.505210838544172e-08);
+    q = FMADK(SK, q, g, 2.755731922398589e-07);
+    q = FMADK(SK, q, g, 2.7557319223985893e-06);
+    q = FMADK(SK, q, g, 2.48015873015873e-05);
+    q = FMADK(SK, q, g, 0.0001984126984126984);
+    q = FMADK(SK, q, g, 0.001388888888888889);
+    q = FMADK(SK, q, g, 0.008333333333333333);
+    q = FMADK(SK, q, g, 0.041666666666666664);
+    q = FMADK(SK, q, g, 0.16666666666666666);
     q = fmad_(q, g, 0.5);
     q = fmad_(q, g, 1.0);
     q = fmad_(q, g, 1.0);

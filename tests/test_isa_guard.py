@@ -38,9 +38,16 @@ def test_checker_rejects_a_work_item_kept_in_a_vgpr():
     bad = GOOD.replace("v_mov_b32_e32 v2, s6\n", "v_add_u32_e32 v2, 1, v17\n")        # pass number from a long-lived VGPR
     (name, body), = list(check_isa.instances(bad))
     assert any("agent-scope store" in e for e in check_isa.check(name, body)[0])
-    bad = GOOD.replace("v_mov_b32_e32 v2, s6\n", "v_mov_b32_e32 v2, s6\n\tscratch_store_dword off, v2, off offset:8\n")
+    # a copy of a scalar spilled lane by lane and taken for wave-uniform again after the reload: round 2's bug
+    spill = "v_mov_b32_e32 v2, s6\n\tscratch_store_dword off, v2, off offset:8\n"
+    back = "\tscratch_load_dword v7, off, off offset:8\n\ts_waitcnt vmcnt(0)\n\tv_readfirstlane_b32 s9, v7\n\ts_endpgm"
+    bad = GOOD.replace("v_mov_b32_e32 v2, s6\n", spill).replace("\ts_endpgm", back)
     (name, body), = list(check_isa.instances(bad))
     assert any("scratch store" in e for e in check_isa.check(name, body)[0])
+    # the same store is fine for a per-lane variable that only STARTS from a scalar (reloaded and used lane by lane)
+    fine = GOOD.replace("v_mov_b32_e32 v2, s6\n", spill).replace("\ts_endpgm", "\tscratch_load_dword v7, off, off offset:8\n\tv_add_u32_e32 v7, 1, v7\n\ts_endpgm")
+    (name, body), = list(check_isa.instances(fine))
+    assert check_isa.check(name, body)[0] == []
 
 
 def test_every_kernel_instance_of_the_library_passes():

@@ -10,7 +10,9 @@ ISA of EVERY k_render / wf_intersect instance (hipcc -S output), that the compil
   2. the data operand of every agent-scope store (global_store_dword ... sc1: tile_done[] publish, counter resets) was
      moved from a scalar register or an immediate in the SAME basic block -- no long-lived VGPR copy of a pass number;
   3. no VGPR that is a plain copy of a scalar register (v_mov_b32 vX, sY) is stored to scratch in the block it was
-     copied in (a spilled copy of a wave-uniform value is exactly the round-2 bug).
+     copied in AND read back from that slot as a wave-uniform (v_readfirstlane_b32, or the data of an agent-scope store): a
+     spilled copy of a wave-uniform value is exactly the round-2 bug.  (A per-lane variable that only starts from a scalar --
+     the suspend schedule's sample counter -- may be initialised that way.)
 
 usage: python tools/check_isa.py file.s [file.s ...]   -> exit 1 and a report if any instance fails."""
 import re
@@ -49,6 +51,31 @@ def regs_of(tok):
 def operands(inst):
     parts = inst.split(None, 1)
     return [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+
+
+def uniform_use_of_slot(L, slot):
+    """index of a v_readfirstlane_b32 (or the data of an agent-scope store) fed by a reload of scratch slot `slot`, or None"""
+    for i, ins in enumerate(L):
+        if not ins.startswith("scratch_load") or not re.search(r"offset:%s\b" % slot, ins):
+            continue
+        dst = set().union(*[regs_of(o) for o in operands(ins)[:1]])
+        for j in range(i + 1, min(len(L), i + 200)):
+            nxt = L[j]
+            if nxt.startswith(".LBB"):
+                break
+            nops = operands(nxt)
+            if not nops:
+                continue
+            op = nxt.split()[0]
+            if op == "v_readfirstlane_b32" and len(nops) > 1 and regs_of(nops[1]) & dst:
+                return j
+            if op == "global_store_dword" and re.search(r"\bsc1\b", nxt) and len(nops) > 1 and regs_of(nops[1]) & dst:
+                return j
+            if not op.startswith(("global_store", "scratch_store", "ds_write", "buffer_store", "flat_store", "s_", "v_cmp")) and regs_of(nops[0]) & dst:
+                dst = dst - regs_of(nops[0])           # redefined
+                if not dst:
+                    break
+    return None
 
 
 def check(name, body):
@@ -102,7 +129,15 @@ def check(name, body):
             for o in ops:
                 for r in regs_of(o):
                     if r in copies:
-                        errs.append("scratch store at #%d (%s): v%d is a copy of %s made in this block" % (i, ins, r, copies[r]))
+                        # a per-lane variable that merely STARTS from a scalar (the suspend schedule's sample counter = the work
+                        # item's first sample) is stored like this too.  What made round 2 hang is the way back: the slot reloaded
+                        # and taken for wave-uniform again.
+                        m = re.search(r"offset:(\d+)", ins)
+                        slot = m.group(1) if m else "0"
+                        use = uniform_use_of_slot(L, slot)
+                        if use is not None:
+                            errs.append("scratch store at #%d (%s): v%d is a copy of %s made in this block, and the slot is read back as a wave-uniform at #%d (%s)" % (
+                                i, ins, r, copies[r], use, L[use]))
             continue
         if ops:
             for r in regs_of(ops[0]):
