@@ -30,6 +30,11 @@ Extra objects:
                    launch count / live kernel time is re-derived with THIS run's HIP-event time.
   "cpu_baseline"   the CPU oracle (port of the reference path) timed on this host's cores on a bounded
                    sample of the same workload; rank 0, N = 1 only.
+  "configs"        the other BASELINE.json configs on this GPU (N = 1 only, untimed side runs after the headline's timed
+                   region, which they do not touch): config 1 (Cornell box 256x256, 4 bounces, 16 spp), config 3 (MESH-100k
+                   through pt_add_obj, 1080p, 8 bounces), config 4 at N = 1 (Cornell box 3840x2160) and config 5 (MESH-1M
+                   through pt_add_obj, 1080p, 16 bounces); each with ms_per_step, msamples_per_s, mean_path_segments, its
+                   40-B/sample HBM roofline, and roofline_valu / traffic from its profiles/counters.json entry.
 """
 import argparse
 import json
@@ -73,13 +78,29 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share cuda:0 and the exchange runs over gloo on host copies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collective-timeout", type=float, default=180.0, help="N > 1: seconds any rendezvous / collective phase may take before the rank exits non-zero")
+    ap.add_argument("--no-band-check", action="store_true", help="skip the one-rank band render that proves the frame equals an N = 1 render")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side runs of BASELINE configs 1, 3, 4 (N = 1) and 5")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
 
 def cpu_baseline(width, height, bounces, target_s):
     """The oracle (C port of prog.cl's gen_ray/trace_ray incl. the reference's own kd-tree
-    traversal) on all host cores, bounded sample of the same workload."""
+    traversal) on all host cores, bounded sample of the same workload.  Built here, for THIS host
+    (oracle/Makefile target `native`: -O3 -march=native); if that build fails the -O2 library
+    the tests use is timed instead, and `sample` says which."""
+    import subprocess
+    import tempfile
+    flags = "-O2 -mfma -ffp-contract=off (oracle/libpt_oracle.so: the native build failed)"
+    tmp = tempfile.mkdtemp(prefix="ptamd_oracle_")
+    so = os.path.join(tmp, "libpt_oracle_native.so")
+    try:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "native", "NATIVE_OUT=" + so], check=True, capture_output=True, timeout=120)
+        os.environ["PT_ORACLE_LIB"] = so
+        flags = "gcc -O3 -march=native -ffp-contract=off, built on this host"
+    except (OSError, subprocess.SubprocessError):
+        pass
     from oracle import oracle_py as O
     spec = scenes.cornell_box()
     osc = O.load_scene(spec)
@@ -99,8 +120,8 @@ def cpu_baseline(width, height, bounces, target_s):
         t1 += time.time() - t0
         spp += extra
     samples = width * height * spp
-    return {"value": samples / t1 / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "Cornell box %dx%d, %d bounces, %d spp (full frame), oracle/pt_oracle.c mode 0, %.1f s" % (width, height, bounces, spp, t1)}
+    return {"value": samples / t1 / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "flags": flags,
+            "sample": "Cornell box %dx%d, %d bounces, %d spp (full frame), oracle/pt_oracle.c mode 0 (%s), %.1f s" % (width, height, bounces, spp, flags, t1)}
 
 
 def kernel_source_sha():
@@ -132,6 +153,96 @@ def tracked_counters(W, H, B, spp, prefix="cornell"):
     return c
 
 
+def valu_roofline(counters, mean_launch_ms):
+    """VALU-issue roofline from a tracked counter entry and a live kernel time."""
+    ipc = counters["valu_insts_per_launch"] / N_SIMD / (mean_launch_ms * 1e-3 * counters["shader_clock_hz"])
+    return {"bound": "valu_issue", "achieved": ipc, "peak": VALU_PEAK_PER_SIMD_CYCLE,
+            "unit": "VALU instructions per SIMD-cycle", "frac": ipc / VALU_PEAK_PER_SIMD_CYCLE,
+            "active_lane_fraction": counters["active_lane_fraction"],
+            "valu_insts_per_launch": counters["valu_insts_per_launch"],
+            "l2_hit_rate": counters.get("l2_hit_rate"),
+            "source": counters["source"], "measured_at": counters["measured_at"], "stale": counters["stale"]}
+
+
+def mesh_scene_through_add_obj(ntris, W, H, device, workdir):
+    """BASELINE configs 3 / 5 as they are worded: the Cornell walls authored with add_Triangle (main.cpp:793-815) and the
+    mesh written as OBJ+MTL (Kd/Ks/Ke/Ns/Kn/Kk/Tp) and loaded with pt_add_obj (main.cpp:552-617).  Identity transform:
+    the loader then authors exactly the triangles of scenes.displaced_grid_mesh(), the scene profiles/counters.json was
+    measured on.  Returns (scene, seconds spent in pt_add_obj, seconds in upload_Triangles)."""
+    path, _, _, _ = scenes.write_grid_mesh_obj(ntris, workdir)
+    sc = api.Scene(W, H, device=device)
+    for m in scenes.BUILTIN_MATERIALS:
+        sc.add_Material(*m)
+    wv, wm = scenes.cornell_walls()
+    sc.add_Triangles(api.triangles_from_vertices(wv, wm))
+    sc.end_Obj()
+    t0 = time.perf_counter()
+    sc.add_Obj(path, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 0.0, 0.0)
+    t1 = time.perf_counter()
+    sc.upload_Triangles()
+    sc.sync()
+    t2 = time.perf_counter()
+    sc.upload_Materials()
+    sc.set_view(60.0, 0.0, 0.0, (0.0, 0.0, 0.0))
+    return sc, t1 - t0, t2 - t1
+
+
+def run_config(name, workload, make_scene, W, H, B, spp, steps, counters_key):
+    """One BASELINE config on this GPU: `steps` timed launches of `spp` samples after one warm-up launch."""
+    made = make_scene()
+    sc, extra = (made[0], {"add_obj_ms": made[1] * 1e3, "upload_triangles_ms": made[2] * 1e3}) if isinstance(made, tuple) else (made, {})
+    sc.iterations = B
+    sc.set_option("timing", 1)
+    sc.render(spp)
+    sc.sync()
+    sc.current_sample = 0
+    sc.seed_default()
+    sc.set_option("reset_stats", 1)
+    sc.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sc.render(spp)
+    sc.sync()
+    dt = time.perf_counter() - t0
+    segs, samples, kms, launches = sc.stat("segments"), sc.stat("samples"), sc.stat("kernel_ms"), sc.stat("kernel_launches")
+    assert samples == float(W) * H * spp * steps, (name, samples)
+    mean_launch_ms = kms / launches
+    bytes_per_launch = MEGA_BYTES_PER_SAMPLE * (samples / launches)
+    achieved = bytes_per_launch / (mean_launch_ms * 1e-3) / 1e9
+    c = tracked_counters(W, H, B, spp, prefix=counters_key) if counters_key else None
+    out = {"config": name, "workload": workload, "steps": steps, "spp_per_step": spp, "ms_per_step": dt / steps * 1e3,
+           "msamples_per_s": samples / dt / 1e6, "mean_path_segments": segs / samples, "msegments_per_s": segs / dt / 1e6,
+           "kernel": {"name": "k_render", "node_mode": int(sc.stat("node_mode")), "waves_per_simd": int(sc.stat("waves_per_simd")),
+                      "bvh_nodes": int(sc.stat("bvh_nodes")), "lds_bytes": int(sc.stat("lds_bytes")), "mean_launch_ms": mean_launch_ms},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": (c["hbm_bytes_per_launch"] if c and not c["stale"] else None),
+                        "traffic_note": (c.get("hbm_note") if c else None),
+                        "algorithmic_bytes_per_launch": bytes_per_launch, "model": "SURVEY 8(d): megakernel 40 B/sample"},
+           "roofline_valu": valu_roofline(c, mean_launch_ms) if c else None}
+    out.update(extra)
+    sc.close()
+    return out
+
+
+def all_configs(device):
+    """BASELINE.json configs[0], [2], [3] (at N = 1) and [4]; configs[1] is the headline itself."""
+    import shutil
+    import tempfile
+    cb = scenes.cornell_box
+    work = tempfile.mkdtemp(prefix="ptamd_bench_")
+    try:
+        return [
+            run_config("config 1", "Cornell box, 256x256, 4 bounces, 16 spp per step", lambda: api.Scene(256, 256, device=device).load(cb()), 256, 256, 4, 16, 16, None),
+            run_config("config 3", "MESH-100k (OBJ+MTL through pt_add_obj, 100,352 + 12 triangles), 1920x1080, 8 bounces, 16 spp per step",
+                       lambda: mesh_scene_through_add_obj(100000, 1920, 1080, device, work), 1920, 1080, 8, 16, 4, "mesh100k"),
+            run_config("config 4 at N=1", "Cornell box, 3840x2160, 8 bounces, 16 spp per step", lambda: api.Scene(3840, 2160, device=device).load(cb()), 3840, 2160, 8, 16, 3, None),
+            run_config("config 5", "MESH-1M (OBJ+MTL through pt_add_obj, 1,002,528 + 12 triangles), 1920x1080, 16 bounces, 8 spp per step",
+                       lambda: mesh_scene_through_add_obj(1000000, 1920, 1080, device, work), 1920, 1080, 16, 8, 4, "mesh1m"),
+        ]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -147,12 +258,19 @@ def main():
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
     comm_dev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
+    from opencl_path_tracer_amd.distributed import TileMap, Watchdog, band_context, band_pixel_ids, exchange_frame, frame_matches_band
+
+    def guarded(what):          # every phase that can block on another rank is bounded: a missing rank fails the job
+        return Watchdog(args.collective_timeout if world > 1 else 0.0, what, rank)
+
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        with guarded("torch.distributed rendezvous"):
+            if args.rehearse_on_one_gpu:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.collective_timeout))
+            else:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=args.collective_timeout))
 
     W, H, B = args.width, args.height, args.bounces
     spec = scenes.cornell_box()
@@ -165,7 +283,6 @@ def main():
 
     # device memory and stream are torch's: the radiance slab is a torch tensor so that RCCL
     # (torch.distributed) can gather it; padded to the largest rank's pixel count.
-    from opencl_path_tracer_amd.distributed import TileMap, exchange_frame
     tmap = TileMap(W, H, world, ROWS_PER_BLOCK)
     npix = sc.local_pixels
     assert npix == tmap.count(rank)
@@ -178,33 +295,46 @@ def main():
     frame = torch.empty((W * H + 1, 4), dtype=torch.float32, device=comm_dev) if world > 1 else None
     scatter_index = tmap.gather_index(comm_dev) if world > 1 else None
 
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    def sync_all(what="barrier + synchronize"):
+        with guarded(what):
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
 
     use_cabi = world > 1 and args.exchange == "cabi" and not args.rehearse_on_one_gpu
     exchange_note = None
     if use_cabi:          # the library's own RCCL communicator; torch only carries the 128-byte id
-        # Every rank must take the same path: a rank that cannot bind RCCL / create the communicator says so, the flags are
-        # reduced, and if ANY rank failed ALL ranks use torch's all-gather instead -- loudly: stderr, and "exchange" /
-        # "exchange_note" in the JSON line say which path produced the number.
-        ok, why = 1, ""
-        try:
-            box = [api.comm_unique_id() if rank == 0 else None]
-        except api.PtError as e:
-            box, ok, why = [None], 0, "pt_comm_unique_id: %s" % e
-        dist.broadcast_object_list(box, src=0)
-        if box[0] is None:
-            ok, why = 0, why or "rank 0 could not create a communicator id"
-        if ok:
-            try:
-                sc.comm_init(box[0])
-            except api.PtError as e:
-                ok, why = 0, "pt_comm_init: %s" % e
+        # Every rank must take the same path, and a rank that cannot take part must be found BEFORE anyone enters
+        # ncclCommInitRank (the others would block in it): (1) every rank probes the RCCL binding (pt_comm_available: no
+        # collective), (2) the flags are MIN-reduced, (3) only if all can, rank 0 creates the id and all ranks call
+        # pt_comm_init -- under the watchdog, like every phase that waits for another rank.  Any failure switches ALL ranks
+        # to torch's all-gather, loudly: stderr, and "exchange" / "exchange_note" in the JSON line say which path ran.
+        ok, why = api.comm_available()
+        ok = 1 if ok else 0
         flag = torch.tensor([ok], dtype=torch.int32, device=comm_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        with guarded("capability all_reduce"):
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [api.comm_unique_id()]
+                except api.PtError as e:
+                    why = "pt_comm_unique_id: %s" % e
+            with guarded("broadcast of the communicator id"):
+                dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
+                ok, why = 0, why or "rank 0 could not create a communicator id"
+            else:
+                try:
+                    with guarded("pt_comm_init (ncclCommInitRank)"):
+                        sc.comm_init(box[0])
+                except api.PtError as e:
+                    ok, why = 0, "pt_comm_init: %s" % e
+            flag = torch.tensor([ok], dtype=torch.int32, device=comm_dev)
+            with guarded("communicator all_reduce"):
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             use_cabi = False
             exchange_note = "C-ABI exchange unavailable (%s): torch.distributed all_gather_into_tensor used instead" % (why or "another rank failed")
@@ -232,9 +362,37 @@ def main():
     for _ in range(args.steps):
         sc.render(args.spp_per_step)
     out = exchange()
-    sync_all()
+    sync_all("timed region: render + exchange")
     dt = time.perf_counter() - t0
     timed_stats = (sc.stat("segments"), sc.stat("samples"), sc.stat("kernel_ms"), sc.stat("kernel_launches"))
+
+    # ---- the exchange alone (untimed repeat of the final step of the timed region: same buffers, same result)
+    exchange_ms = None
+    if world > 1:
+        sync_all()
+        t1 = time.perf_counter()
+        out = exchange()
+        sync_all("exchange alone")
+        exchange_ms = (time.perf_counter() - t1) * 1e3
+
+    # ---- self-validation: the frame of an N-rank run is bit-identical to a one-rank render by construction (seeds and
+    # pixel ids are those of the global frame) -- so prove it: rank 0 renders a 24-row band as a ONE-rank context, same
+    # seeds, same spp, and compares it bit for bit with those rows of the assembled frame
+    frame_matches_n1, band = None, None
+    if rank == 0 and not args.no_band_check:
+        band = band_context(H, 24)
+        frame_np = sc.read_frame() if (use_cabi or world == 1) else out.detach().cpu().numpy()
+        bsc = api.Scene(W, H, device=gpu_index, **band).load(spec)
+        bsc.iterations = B
+        if args.lds_scene >= 0:
+            bsc.set_option("lds_scene", args.lds_scene)
+        bsc.set_option("variant", args.variant)
+        for _ in range(args.steps):
+            bsc.render(args.spp_per_step)
+        frame_matches_n1 = frame_matches_band(frame_np, bsc.read_colors(), band_pixel_ids(W, H, band))
+        bsc.close()
+        if not frame_matches_n1:
+            print("[bench] the assembled frame DIFFERS from a one-rank render of rows %d..%d" % (band["rank"] * 24, band["rank"] * 24 + 23), file=sys.stderr, flush=True)
 
     # ---- side measurement (untimed, not part of `value`): the other formulation, same workload
     other = None
@@ -255,16 +413,20 @@ def main():
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
     stats = torch.tensor(list(timed_stats), dtype=torch.float64, device=comm_dev)
-    kmax = stats[2:3].clone()
+    kmax, kmin = stats[2:3].clone(), stats[2:3].clone()
+    xmax = torch.tensor([exchange_ms or 0.0], dtype=torch.float64, device=comm_dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        with guarded("reduction of the timing scalars"):
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(kmin, op=dist.ReduceOp.MIN)
+            dist.all_reduce(xmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
     segs, samples, kms_sum, launches = [float(x) for x in stats.tolist()]
     total_spp = args.steps * args.spp_per_step
     assert samples == float(W) * H * total_spp, (samples, W * H * total_spp)
-    if use_cabi:
+    if use_cabi or world == 1:
         checksum = float(sc.read_frame()[:, :3].astype(np.float64).sum())
     else:
         checksum = float(out[:, :3].double().sum().item())
@@ -296,6 +458,15 @@ def main():
                        "variant": "megakernel" if args.variant == 0 else "wavefront",
                        "kernel": "k_render (fused gen_ray+trace_ray, persistent per pixel)" if args.variant == 0 else "wf_intersect (+wf_generate, wf_shade)"},
             "mean_path_segments": dbar, "msegments_per_s": segs / dt / 1e6, "radiance_checksum": checksum,
+            # N-rank self-validation (also printed, trivially, at N = 1): a 24-row band rendered by a one-rank context on rank 0
+            # == the same rows of the assembled frame, bit for bit; which exchange ran; the slowest and the fastest rank's kernel
+            # time over the timed steps; the exchange alone (max over ranks, untimed repeat)
+            "frame_matches_n1": frame_matches_n1,
+            "band_check": None if band is None else {"rows": [band["rank"] * band["rows_per_block"], min(H, (band["rank"] + 1) * band["rows_per_block"]) - 1],
+                                                      "context": "pt_create_tiled(rank=%d, world=%d, rows_per_block=%d)" % (band["rank"], band["world"], band["rows_per_block"])},
+            "exchange_path": "none (one rank: the colors buffer is the frame)" if world == 1 else ("pt_gather_frame" if use_cabi else ("gloo all_gather (rehearsal)" if args.rehearse_on_one_gpu else "torch all_gather_into_tensor")),
+            "kernel_ms_per_rank": {"min": float(kmin.item()), "max": float(kmax.item())},
+            "exchange_ms": (float(xmax.item()) if world > 1 else 0.0),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_render" if args.variant == 0 else "wf_intersect", "mean_launch_ms": mean_launch_ms,
@@ -305,12 +476,7 @@ def main():
         }
         if counters is not None:
             # the bound the megakernel actually has: VALU issue, with this run's kernel time
-            ipc = counters["valu_insts_per_launch"] / N_SIMD / (mean_launch_ms * 1e-3 * counters["shader_clock_hz"])
-            line["roofline_valu"] = {"bound": "valu_issue", "achieved": ipc, "peak": VALU_PEAK_PER_SIMD_CYCLE,
-                                     "unit": "VALU instructions per SIMD-cycle", "frac": ipc / VALU_PEAK_PER_SIMD_CYCLE,
-                                     "active_lane_fraction": counters["active_lane_fraction"],
-                                     "valu_insts_per_launch": counters["valu_insts_per_launch"],
-                                     "source": counters["source"], "measured_at": counters["measured_at"], "stale": counters["stale"]}
+            line["roofline_valu"] = valu_roofline(counters, mean_launch_ms)
         if other is not None:
             # the other formulation's own HBM roofline.  Wavefront: SURVEY 8(d)'s stream model, 32 B/sample + 200 B/segment
             # over ALL its kernels (generate, intersect, shade) per step; traffic = the tracked PMC bytes of one sample pass
@@ -329,12 +495,18 @@ def main():
                                  "traffic": otraffic, "algorithmic_bytes_per_step": obytes, "model": omodel,
                                  "time": "wall clock of the untimed side run (all launches of a step)"}
             line["other_variant"] = other
+        if world == 1 and not args.no_configs:
+            sc.close()
+            line["configs"] = all_configs(gpu_index)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(W, H, B, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        with guarded("final barrier"):
+            dist.barrier()
         dist.destroy_process_group()
+    if frame_matches_n1 is False:
+        raise SystemExit(5)
 
 
 if __name__ == "__main__":

@@ -73,6 +73,10 @@ void pt_triangles_init(pt_triangle* out, const float* verts, const uint16_t* mat
  * screen_width/height: main.cpp:20-21,30-39) passed as arguments */
 void pt_camera_init(pt_camera* c, float fov, float yaw, float pitch, const float shift[3],
                     int32_t width, int32_t height);
+/* The side effect of the reference's Camera() (main.cpp:334-336): shift += ahead * forward + right * rightward + up * upward
+ * along the rotated unit axes, in place -- what moves the camera when the key handlers (main.cpp:1189-1209) set the three
+ * globals.  Call it before pt_camera_init, once per Camera() the reference would have constructed. */
+void pt_camera_move(float shift[3], float yaw, float pitch, float forward, float rightward, float upward);
 
 /* ---- context: Scene::init_Scene, main.cpp:456-528 --------------------------------- */
 /* Selects HIP device `device`, allocates rays (32 B/px), rnds (4 B/px), colors (16 B/px)
@@ -142,6 +146,10 @@ int pt_resolve_ldr(pt_context* ctx, int32_t which, float* out_rgba, int64_t npix
  * that a one-rank context serves its colors buffer (which IS the frame) and a tiled context returns NULL / PT_EINVAL
  * until pt_gather_frame has run again -- never a frame older than colors. */
 #define PT_COMM_ID_BYTES 128
+/* PT_OK if librccl could be bound in this process (dlopen + the five entry points), PT_ECOMM otherwise (pt_last_error(NULL)
+ * says why).  Touches no collective: every rank can ask BEFORE any of them enters ncclCommInitRank, so that a rank that cannot
+ * take part is found while the others can still be told (a rank missing from ncclCommInitRank blocks all the others). */
+int pt_comm_available(void);
 int pt_comm_unique_id(void* id128);                                  /* ncclGetUniqueId */
 int pt_comm_init(pt_context* ctx, const void* id128);                /* ncclCommInitRank(world, id, rank) of pt_create_tiled */
 int pt_gather_frame(pt_context* ctx);
@@ -243,6 +251,11 @@ int pt_debug_scene_copy(const pt_context* ctx, pt_triangle* tris, pt_material* m
 int pt_debug_encounter_rank(const pt_context* ctx, int32_t* out, int64_t n);
 /* after a counting launch (option count_work = 1, pt_render): per 8x8 tile of the local frame, shader-clock cycles / 64 spent on it */
 int pt_debug_tile_cost(pt_context* ctx, uint32_t* out, int64_t n_tiles);
+/* What pt_render(nsamples) would launch on a device of cu_count compute units (0: the context's own; works on a host-only
+ * context): out[8] = { threads per workgroup, waves per SIMD, schedule (0 lockstep, 1 suspend), samples per (pass, tile)
+ * work item (0: whole tiles), resident waves, tiles, node mode, dynamic LDS bytes }.  Lets CPU tests pin the launch policy
+ * of a rank of an N-GPU job. */
+int pt_debug_launch_plan(pt_context* ctx, int32_t nsamples, int32_t cu_count, int64_t out[8]);
 /* frame assembly: out[gid] = index into the rank-major all-gather buffer (slab_stride pixels per rank) that
  * global pixel gid is read from -- the host statement of the de-interleave kernel's map (no device work) */
 int pt_debug_gather_index(int32_t width, int32_t height, int32_t world, int32_t rows_per_block, int64_t slab_stride, int64_t* out);

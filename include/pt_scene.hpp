@@ -6,8 +6,11 @@
 //
 // Differences forced by leaving OpenCL/GLUT behind:
 //   * the globals the reference's Camera() and trace_rays() read (screen_width/height,
-//     iterations, current_sample, global_fov/yaw/pitch/shift: main.cpp:20-39) are members of
-//     Scene (`globals`); init_Scene takes the frame size;
+//     iterations, current_sample, global_fov/yaw/pitch/shift and the per-frame movement
+//     global_forward/rightward/upward: main.cpp:20-39) are members of Scene (`globals`);
+//     Camera(Globals&) has the reference constructor's side effect -- it adds the movement into
+//     global_shift along the rotated axes (main.cpp:334-336) -- so the key handlers of
+//     main.cpp:1189-1224 move the camera exactly as they do there; init_Scene takes the frame size;
 //   * failures throw std::runtime_error instead of exit(1) (main.cpp:502, 560);
 //   * the radiance is read back with download_colors() instead of being blitted from a GL
 //     texture (main.cpp:519, 1019-1039).
@@ -39,12 +42,19 @@ struct Globals {                                       // the shipped values of 
     int iterations = 1;                                                                  // main.cpp:27
     float global_fov = 75.0f;                                                            // main.cpp:30
     float global_yaw = (float)(-13.800002 - 50), global_pitch = (float)(5.599997 + 10);   // main.cpp:31-32 (double arithmetic, narrowed)
+    float global_forward = 0, global_rightward = 0, global_upward = 0;                   // main.cpp:36-38: this frame's movement (speed * dt or 0, main.cpp:1189-1209)
     cl_float3 global_shift = {{265.055481f, 162.305969f, 360.414001f, 0.0f}};            // main.cpp:39
     // (the "canonical" view the reference keeps in comments, main.cpp:33-35,40: fov 60, yaw 0, pitch 0, shift 0)
 };
 
 struct Camera : pt_camera {                            // main.cpp:306-348
     Camera() { XM = YM = 0; }
+    // the reference's Camera(): FIRST the movement accumulates into global_shift (main.cpp:334-336), then the eye is placed
+    explicit Camera(Globals& g) {
+        pt_camera_move(g.global_shift.s, g.global_yaw, g.global_pitch, g.global_forward, g.global_rightward, g.global_upward);
+        pt_camera_init(this, g.global_fov, g.global_yaw, g.global_pitch, g.global_shift.s, g.screen_width, g.screen_height);
+    }
+    // a view of the globals as they stand (no movement applied)
     explicit Camera(const Globals& g) { pt_camera_init(this, g.global_fov, g.global_yaw, g.global_pitch, g.global_shift.s, g.screen_width, g.screen_height); }
 };
 
@@ -88,7 +98,8 @@ public:
         trace_rays();
         ck(pt_set_current_sample(ctx, current_sample() + 1));
     }
-    // nsamples x render() as one persistent launch (same result, bit for bit)
+    // nsamples x render() as one persistent launch (same result, bit for bit, for a camera at rest; a moving camera -- a
+    // non-zero global_forward / rightward / upward -- moves ONCE per call here, where n x render() would move it n times)
     void render(int nsamples) {
         camera = Camera(globals);
         ck(pt_render(ctx, &camera, globals.iterations, nsamples));

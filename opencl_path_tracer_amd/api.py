@@ -40,15 +40,15 @@ assert MATERIAL.itemsize == 80 and RAY.itemsize == 32 and TRIANGLE.itemsize == 8
 
 # every symbol include/pt_api.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "pt_material_init", "pt_triangle_init", "pt_triangles_init", "pt_camera_init", "pt_create", "pt_create_tiled", "pt_destroy",
+    "pt_material_init", "pt_triangle_init", "pt_triangles_init", "pt_camera_init", "pt_camera_move", "pt_create", "pt_create_tiled", "pt_destroy",
     "pt_last_error", "pt_device_info", "pt_add_material", "pt_add_triangle", "pt_add_triangles", "pt_end_obj",
     "pt_add_obj", "pt_upload_triangles", "pt_upload_materials", "pt_seed_default", "pt_upload_seeds",
     "pt_generate_rays", "pt_trace_rays", "pt_render", "pt_set_current_sample", "pt_get_current_sample", "pt_sync",
     "pt_local_pixel_count", "pt_local_pixel_ids", "pt_read_colors", "pt_read_rnds", "pt_read_rays",
     "pt_resolve_ldr", "pt_bind_framebuffer", "pt_device_colors", "pt_device_rnds", "pt_set_stream",
-    "pt_set_option", "pt_get_stat", "pt_debug_bvh_sizes", "pt_debug_bvh_copy", "pt_debug_wide_nodes", "pt_debug_encounter_rank", "pt_debug_tile_cost",
+    "pt_set_option", "pt_get_stat", "pt_debug_bvh_sizes", "pt_debug_bvh_copy", "pt_debug_wide_nodes", "pt_debug_encounter_rank", "pt_debug_tile_cost", "pt_debug_launch_plan",
     "pt_debug_scene_sizes", "pt_debug_scene_copy", "pt_debug_closest_hit",
-    "pt_slab_pixel_count", "pt_frame_size", "pt_comm_unique_id", "pt_comm_init", "pt_gather_frame", "pt_device_frame", "pt_read_frame",
+    "pt_slab_pixel_count", "pt_frame_size", "pt_comm_available", "pt_comm_unique_id", "pt_comm_init", "pt_gather_frame", "pt_device_frame", "pt_read_frame",
     "pt_write_pfm", "pt_write_ppm", "pt_image_write_pfm", "pt_image_write_ppm", "pt_debug_gather_index", "pt_debug_deinterleave",
 ]
 
@@ -76,6 +76,7 @@ def _load():
     sig("pt_triangle_init", None, vp, fp, fp, fp, C.c_uint16)
     sig("pt_triangles_init", None, vp, vp, vp, i64)
     sig("pt_camera_init", None, vp, f32, f32, f32, fp, i32, i32)
+    sig("pt_camera_move", None, fp, f32, f32, f32, f32, f32)
     sig("pt_create", C.c_int, C.c_int, i32, i32, C.POINTER(vp))
     sig("pt_create_tiled", C.c_int, C.c_int, i32, i32, i32, i32, i32, C.POINTER(vp))
     sig("pt_destroy", None, vp)
@@ -113,11 +114,13 @@ def _load():
     sig("pt_debug_wide_nodes", C.c_int, vp, vp, i64, C.POINTER(i64))
     sig("pt_debug_encounter_rank", C.c_int, vp, vp, i64)
     sig("pt_debug_tile_cost", C.c_int, vp, vp, i64)
+    sig("pt_debug_launch_plan", C.c_int, vp, i32, i32, vp)
     sig("pt_debug_scene_sizes", C.c_int, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64))
     sig("pt_debug_scene_copy", C.c_int, vp, vp, vp, vp)
     sig("pt_debug_closest_hit", C.c_int, vp, vp, i64, vp, vp)
     sig("pt_slab_pixel_count", C.c_int, vp, C.POINTER(i64))
     sig("pt_frame_size", C.c_int, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64))
+    sig("pt_comm_available", C.c_int)
     sig("pt_comm_unique_id", C.c_int, vp)
     sig("pt_comm_init", C.c_int, vp, vp)
     sig("pt_gather_frame", C.c_int, vp)
@@ -164,6 +167,13 @@ def Camera(fov, yaw, pitch, shift, width, height):
     return c
 
 
+def camera_move(shift, yaw, pitch, forward, rightward, upward):
+    """main.cpp:334-336: the movement the reference's Camera() adds into global_shift; returns the new shift (3 floats)."""
+    v = (C.c_float * 3)(*[float(x) for x in shift])
+    LIB.pt_camera_move(v, float(yaw), float(pitch), float(forward), float(rightward), float(upward))
+    return (v[0], v[1], v[2])
+
+
 def triangles_from_vertices(verts, mati):
     """(n,3,3) float32 vertices + (n,) material indices -> (n,) TRIANGLE records."""
     verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
@@ -171,6 +181,12 @@ def triangles_from_vertices(verts, mati):
     out = np.zeros(verts.shape[0], dtype=TRIANGLE)
     LIB.pt_triangles_init(_ptr(out), _ptr(verts), _ptr(mati), verts.shape[0])
     return out
+
+
+def comm_available():
+    """(True, "") if librccl is bound in this process, else (False, why).  No collective is touched."""
+    rc = LIB.pt_comm_available()
+    return (True, "") if rc == PT_OK else (False, (LIB.pt_last_error(None) or b"").decode())
 
 
 def comm_unique_id():
@@ -462,6 +478,13 @@ class Scene:
         out = np.empty(n, dtype=np.int32)
         self._ck(LIB.pt_debug_encounter_rank(self._h, _ptr(out), n))
         return out
+
+    def debug_launch_plan(self, nsamples, cu_count=0):
+        """What render(nsamples) would launch on a device of cu_count compute units (host-only contexts too)."""
+        out = np.zeros(8, dtype=np.int64)
+        self._ck(LIB.pt_debug_launch_plan(self._h, int(nsamples), int(cu_count), _ptr(out)))
+        keys = ("block", "waves_per_simd", "schedule", "chunk_spp", "resident_waves", "tiles", "node_mode", "lds_bytes")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def debug_tile_cost(self):
         """After set_option("count_work", 1) + render(n): per 8x8 tile of the local frame, the shader-clock cycles / 64 its wave spent on it."""

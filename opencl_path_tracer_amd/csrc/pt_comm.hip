@@ -91,6 +91,12 @@ void gather_source_index(int W, int H, int world, int rb, long long slab_stride,
     }
 }
 
+int comm_available(std::string* err) {
+    RcclApi* r = rccl();
+    if (!r->error.empty()) { *err = r->error; return PT_ECOMM; }
+    return PT_OK;
+}
+
 int comm_unique_id(void* id128, std::string* err) {
     RcclApi* r = rccl();
     if (!r->error.empty()) { *err = r->error; return PT_ECOMM; }

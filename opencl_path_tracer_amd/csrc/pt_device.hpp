@@ -17,6 +17,20 @@
 #ifndef PT_GLOBAL_SLAB_FMA
 #define PT_GLOBAL_SLAB_FMA 1
 #endif
+// A/B switch of the 4-wide node visit (1: round 3's form -- decode, then slab test; 0: round 4's, see wide_step)
+#ifndef PT_WIDE_STEP_V1
+#define PT_WIDE_STEP_V1 0
+#endif
+// A/B switches: Trav::round ends a phase early when few lanes are still in it (see round()), per node path
+#ifndef PT_PHASE_SWITCH_GLOBAL
+#define PT_PHASE_SWITCH_GLOBAL 1
+#endif
+#ifndef PT_PHASE_SWITCH_LDS
+#define PT_PHASE_SWITCH_LDS 1
+#endif
+#ifndef PT_WIDE_PREDICATED_STORES
+#define PT_WIDE_PREDICATED_STORES 1
+#endif
 
 namespace ptamd {
 
@@ -268,6 +282,9 @@ struct SceneView {
     // (all three wave-uniform, i.e. scalar registers: which entry an address is, and whose, is read off the address
     // itself -- the stacks start at LDS offset 0, entry k of lane l at (k * BLOCK + l) * 4 -- so that no per-lane
     // pointer rides through the traversal)
+    // phase switching of Trav::round (wave-uniform): the node phase ends early when at most node_min_lanes lanes still descend
+    // and another lane holds a leaf; the leaf phase when at most leaf_min_lanes lanes still hold leaves and another has a node
+    int node_min_lanes, leaf_min_lanes;
     int lds_entries;           // entries per lane in LDS
     unsigned* ovf;             // entry (lds_entries + j) of lane l of this workgroup = ovf[j * ovf_stride + l]
     unsigned ovf_stride;
@@ -350,6 +367,7 @@ struct Trav {
     typedef typename StackOf<MODE>::type StackT;
     static constexpr bool kRef16 = MODE == kNodesLds;
     static constexpr bool kDefer = MODE != kNodesLds;     // see node_step
+    static constexpr bool kPhaseSwitch = MODE == kNodesLds ? (PT_PHASE_SWITCH_LDS != 0) : (PT_PHASE_SWITCH_GLOBAL != 0);   // see round()
     static constexpr int kDone = kRef16 ? 0x7fff : 0x7fffffff;
     f3 P, D, inv;
     float best_t;
@@ -546,6 +564,7 @@ struct Trav {
         else sv.ovf[(size_t)j * sv.ovf_stride + lane_of(at)] = (unsigned)v;
     }
 
+#if PT_WIDE_STEP_V1
     template <bool COUNT>
     PT_DEV void wide_step(const SceneView& sv, WorkCount* wc) {
         const float kWiden = 1.0000005f;
@@ -618,6 +637,117 @@ struct Trav {
         tos += (n > 0 ? n - 1 : -1) * stride;
     }
 
+#else
+    // Round 4: the visit re-counted in CLOCKS (tools/micro/exec_ops.hip: v_fma / v_mul / v_add 2.4-2.9 per wave
+    // instruction, v_cvt / v_cmp / v_cndmask / v_min3 / v_max3 / v_lshlrev 4.2-4.4, a VOP2 v_cndmask on a VCC the SALU wrote 21):
+    //  * decode and slab test are ONE fma per plane: t = q * (step * inv) + (origin * inv - P * inv).  step is a power of
+    //    two, so step * inv is exact; the second term costs one rounding per axis and side, taken once per node (6 fma)
+    //    instead of once per plane (24 fma saved).  The plane the host checked, fl(q * step + origin), no longer exists:
+    //    the effective plane is the real number q * step + origin, at most half an ulp of the coordinate off it --
+    //    1 / 170 of what padded_bounds() adds to every triangle's box (1e-5 of the coordinate), and the new rounding of
+    //    (origin * inv + c) is one more half-ulp of P * inv out of the four that c is widened by (setup());
+    //  * the three exponent bytes become step factors with one SDWA shift each (byte select in the instruction);
+    //  * hit <=> max(tn, 0) <= min(tf, lim): one compare, whose VCC feeds the select of the key AND the count of hit
+    //    children (three compares joined on the SALU ended in a 21-clock select);
+    //  * the pushes are predicated stores at tos + (n - j): no address selects.
+    PT_DEV static float exp_byte_step(unsigned eb, int which) {      // 2^(byte - 127): byte << 23
+        unsigned r;
+        if (which == 0) asm("v_lshlrev_b32_sdwa %0, 23, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(eb));
+        else if (which == 1) asm("v_lshlrev_b32_sdwa %0, 23, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(eb));
+        else asm("v_lshlrev_b32_sdwa %0, 23, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(eb));
+        return __int_as_float((int)r);
+    }
+    template <bool COUNT>
+    PT_DEV void wide_step(const SceneView& sv, WorkCount* wc) {
+        const float kWiden = 1.0000005f;
+        // does any lane of the wave come within three entries of the end of its LDS part?  (rare: then every stack
+        // access of this visit goes through the checked accessors)
+        const bool tight = __ballot(entry_of(tos) + 3 >= sv.lds_entries) != 0;
+        const int top = tight ? stack_get(sv, tos) : (int)*reinterpret_cast<const StackT*>(tos);
+        if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; }
+        const char* nb = reinterpret_cast<const char*>(sv.nodes);
+        const unsigned off = (unsigned)cur << 6;
+        const float4 h = *reinterpret_cast<const float4*>(nb + off);
+        const uint4 qa = *reinterpret_cast<const uint4*>(nb + (off + 16u));
+        const uint2 qb = *reinterpret_cast<const uint2*>(nb + (off + 32u));
+        const int4 rf = *reinterpret_cast<const int4*>(nb + (off + 48u));
+        const unsigned eb = (unsigned)__float_as_int(h.w);
+        const float ax = exp_byte_step(eb, 0) * inv.x, ay = exp_byte_step(eb, 1) * inv.y, az = exp_byte_step(eb, 2) * inv.z;
+        const float bnx = fmaf_(h.x, inv.x, cn.x), bny = fmaf_(h.y, inv.y, cn.y), bnz = fmaf_(h.z, inv.z, cn.z);
+        const float bfx = fmaf_(h.x, inv.x, cf.x), bfy = fmaf_(h.y, inv.y, cf.y), bfz = fmaf_(h.z, inv.z, cf.z);
+        const bool ngx = negx(), ngy = negy(), ngz = negz();
+        const unsigned enx = ngx ? qa.y : qa.x, exx = ngx ? qa.x : qa.y;
+        const unsigned eny = ngy ? qa.w : qa.z, exy = ngy ? qa.z : qa.w;
+        const unsigned enz = ngz ? qb.y : qb.x, exz = ngz ? qb.x : qb.y;
+        const float lim = best_t * kWiden;
+        float key[4];
+        int ref[4] = {rf.x, rf.y, rf.z, rf.w};
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float tnx = fmaf_((float)((enx >> (8 * k)) & 0xffu), ax, bnx), tfx = fmaf_((float)((exx >> (8 * k)) & 0xffu), ax, bfx);
+            const float tny = fmaf_((float)((eny >> (8 * k)) & 0xffu), ay, bny), tfy = fmaf_((float)((exy >> (8 * k)) & 0xffu), ay, bfy);
+            const float tnz = fmaf_((float)((enz >> (8 * k)) & 0xffu), az, bnz), tfz = fmaf_((float)((exz >> (8 * k)) & 0xffu), az, bfz);
+            // entry clamped to the ray's origin: then "exit >= entry" includes "exit >= 0", and lim >= 0 always
+            const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f);
+            const float tf = fminf(fminf(fminf(tfx, tfy), tfz) * kWiden, lim);
+            // (no test for "no child": its box is inverted and its reference a harmless leaf -- pt_wide.cpp.  A child
+            // "hit" at tn = +inf -- a ray parallel to a slab it is outside of -- sorts among the misses; should it be
+            // pushed, or a miss in its place, the visit that follows is wasted work, not a wrong answer.)
+            const bool hit = tn <= tf;
+            key[k] = hit ? tn : __builtin_inff();
+            n += hit ? 1 : 0;
+        }
+#define PT_CSWAP(a, b)                                                                        \
+        {                                                                                     \
+            const bool sw = key[a] > key[b];                                                  \
+            const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];                 \
+            const int ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];                   \
+            key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb;                               \
+        }
+        PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+        // the nearest child is a leaf and no leaf is pending: remember it (round() intersects it after the node phase)
+        // and go on with the next child -- fewer node-phase / leaf-phase alternations, as in node_step
+        const bool cap = n > 0 && is_leaf(ref[0]) && pend == 0;
+        pend = cap ? ref[0] : pend;
+        ref[0] = cap ? ref[1] : ref[0];
+        ref[1] = cap ? ref[2] : ref[1];
+        ref[2] = cap ? ref[3] : ref[2];
+        n -= cap ? 1 : 0;
+#if PT_WIDE_PREDICATED_STORES
+        // child j (1 <= j < n) goes to entry top + (n - j): popped nearest first; a missed child is not stored
+        char* const a3 = tos + (n - 3) * stride;        // child 3's entry; children 2 and 1 one and two entries above it
+        if (!tight) {
+            if (1 < n) *reinterpret_cast<StackT*>(a3 + 2 * stride) = (StackT)ref[1];
+            if (2 < n) *reinterpret_cast<StackT*>(a3 + stride) = (StackT)ref[2];
+            if (3 < n) *reinterpret_cast<StackT*>(a3) = (StackT)ref[3];
+        } else {
+            if (1 < n) stack_put(sv, a3 + 2 * stride, ref[1]);
+            if (2 < n) stack_put(sv, a3 + stride, ref[2]);
+            if (3 < n) stack_put(sv, a3, ref[3]);
+        }
+#else
+        // child j (1 <= j < n) goes to entry top + (n - j): popped nearest first; a missed child (j >= n) to top + j, above the
+        // new top, where it is never read -- all three stores are unconditional (no branch in the visit)
+        char* const a1 = tos + (1 < n ? n - 1 : 1) * stride;
+        char* const a2 = tos + (2 < n ? n - 2 : 2) * stride;
+        char* const a3 = tos + (3 < n ? n - 3 : 3) * stride;
+        if (!tight) {
+            *reinterpret_cast<StackT*>(a1) = (StackT)ref[1];
+            *reinterpret_cast<StackT*>(a2) = (StackT)ref[2];
+            *reinterpret_cast<StackT*>(a3) = (StackT)ref[3];
+        } else {
+            stack_put(sv, a1, ref[1]);
+            stack_put(sv, a2, ref[2]);
+            stack_put(sv, a3, ref[3]);
+        }
+#endif
+        cur = n > 0 ? ref[0] : top;
+        tos += (n > 0 ? n - 1 : -1) * stride;
+    }
+
+#endif
     // exact test of packed triangle ti against the ray, keeping the closest (ties: lower rank)
     template <bool COUNT>
     PT_DEV void tri_step(const SceneView& sv, int ti, WorkCount* wc) {
@@ -694,16 +824,38 @@ struct Trav {
         }
     }
 
+    // One round: a node phase (every lane descends until it holds a leaf or has finished), then a leaf phase (the lanes holding
+    // leaves intersect them and pop).  Round 4: a phase ENDS EARLY when few lanes are still in it and another lane is waiting for
+    // the other phase -- the stragglers simply go on in the next round, next to the lanes that come back.  What a while-while
+    // loop loses is its tails: half of all node-body executions ran for four lanes or fewer, and a VALU instruction with at most
+    // 8 active lanes costs 3-4 times what it costs with 9 to 64 (tools/micro/exec_ops.hip).  MESH-100k 841 -> 980 Msamples/s,
+    // MESH-1M 297 -> 353 at node_min_lanes = 8 (profiles/r04/).  The traversal state allows it as it is: round() can be entered
+    // with a node, a leaf or a pending leaf in hand.
+    template <bool COUNT>
+    PT_DEV void step(const SceneView& sv, WorkCount* wc) {
+        if (MODE == kNodesLds) node_step<COUNT, false, kVisitLds>(sv, wc);
+        else if (MODE == kNodesGlobal) node_step<COUNT, true, kVisitGlobal>(sv, wc);
+        else if (MODE == kNodesWide) wide_step<COUNT>(sv, wc);
+        else node_step<COUNT, true, kVisitFlat>(sv, wc);
+    }
     template <bool COUNT>
     PT_DEV void round(const SceneView& sv, WorkCount* wc) {
-        if (MODE == kNodesLds) {
-            while (is_node(cur)) node_step<COUNT, false, kVisitLds>(sv, wc);
-        } else if (MODE == kNodesGlobal) {
-            while (is_node(cur)) node_step<COUNT, true, kVisitGlobal>(sv, wc);
-        } else if (MODE == kNodesWide) {
-            while (is_node(cur)) wide_step<COUNT>(sv, wc);
+        // Every lane that enters a phase takes at least one step of it (so a round always makes progress, whatever the two
+        // thresholds are); after that the phase ends for everybody as soon as at most `min_lanes` lanes are still in it AND some
+        // lane has left it -- with a leaf to intersect, a node to visit, or a finished ray for the caller to replace.
+        if (kPhaseSwitch) {
+            const unsigned long long entered = __ballot(is_node(cur));
+            if (is_node(cur)) {
+                for (;;) {
+                    step<COUNT>(sv, wc);
+                    const bool live = is_node(cur);
+                    if (!live) break;
+                    const unsigned long long lm = __ballot(live);
+                    if (lm != entered && __popcll(lm) <= sv.node_min_lanes) break;
+                }
+            }
         } else {
-            while (is_node(cur)) node_step<COUNT, true, kVisitFlat>(sv, wc);
+            while (is_node(cur)) step<COUNT>(sv, wc);
         }
         if (kDefer && pend != 0) {            // met first, so nearer: intersect it first
             const int v = leaf_bits(pend);
@@ -711,14 +863,29 @@ struct Trav {
             for (int j = 0; j < count; ++j) tri_step<COUNT>(sv, first + j, wc);
             pend = 0;
         }
-        while (is_leaf(cur)) {
-            const int popped = stack_get(sv, tos);     // in flight during the triangle tests
-            const int v = leaf_bits(cur);
-            const int first = v >> 3, count = (v & 7) + 1;
-            for (int j = 0; j < count; ++j) tri_step<COUNT>(sv, first + j, wc);
-            cur = popped;
-            tos -= stride;
+        if (kPhaseSwitch) {
+            const unsigned long long entered = __ballot(is_leaf(cur));
+            if (is_leaf(cur)) {
+                for (;;) {
+                    leaf_step<COUNT>(sv, wc);
+                    const bool live = is_leaf(cur);
+                    if (!live) break;
+                    const unsigned long long lm = __ballot(live);
+                    if (lm != entered && __popcll(lm) <= sv.leaf_min_lanes) break;
+                }
+            }
+        } else {
+            while (is_leaf(cur)) leaf_step<COUNT>(sv, wc);
         }
+    }
+    template <bool COUNT>
+    PT_DEV void leaf_step(const SceneView& sv, WorkCount* wc) {
+        const int popped = stack_get(sv, tos);     // in flight during the triangle tests
+        const int v = leaf_bits(cur);
+        const int first = v >> 3, count = (v & 7) + 1;
+        for (int j = 0; j < count; ++j) tri_step<COUNT>(sv, first + j, wc);
+        cur = popped;
+        tos -= stride;
     }
 };
 
@@ -929,6 +1096,8 @@ PT_DEV void setup_traversal(const RenderParams& p, SceneView* sv, LaneStack<type
     sv->n_flat = p.n_flat;
     sv->lds_nodes = nullptr;
     sv->lds_entries = p.stack_entries;
+    sv->node_min_lanes = p.node_min_lanes;
+    sv->leaf_min_lanes = p.leaf_min_lanes;
     sv->ovf = p.stack_ovf ? p.stack_ovf + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BLOCK : nullptr;
     sv->ovf_stride = (unsigned)p.stack_ovf_lanes;
     float4* lds_flat = reinterpret_cast<float4*>(pt_lds_raw + traversal_nodes_end_dev<MODE, BLOCK>(p));

@@ -126,6 +126,7 @@ struct pt_context {
     int flat_list = 16;        // at most this many big triangles go to the flat list (option flat_list; 0: none)
     int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
     int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 24)
+    int node_min_lanes = -1, leaf_min_lanes = -1;   // phase switching of the while-while rounds (-1: by node path, fill_params)
     int lbvh_ploc = 16;     // device-built trees: PLOC search radius (8 / 16 / 32); 0: Karras' radix tree over the Morton codes
     int lbvh_cluster = 64;  // device-built trees: the top above clusters of this many triangles is rebuilt with the host SAH (0: not)
     int build_threads = 0; // host SAH builder: threads (0: the machine's, at most 16); the tree is the same for any number
@@ -183,6 +184,7 @@ int append_triangles(pt_context* ctx, int64_t n, pt_triangle** tail) {
 // pt_comm.hip
 hipError_t launch_deinterleave(const float4* gathered, float4* frame, int W, int H, int world, int rb, long long slab_stride, hipStream_t stream);
 void gather_source_index(int W, int H, int world, int rb, long long slab_stride, int64_t* out);
+int comm_available(std::string* err);
 int comm_unique_id(void* id128, std::string* err);
 int comm_init(const void* id128, int rank, int world, void** comm_out, std::string* err);
 void comm_destroy(void* comm);
@@ -1296,6 +1298,11 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     // 1680 / 1669 Msamples/s (lockstep 1671); MESH-100k 24 / 32 / 48 -> 600 / 599 / 595 (lockstep 571); MESH-1M 211 / 210 / 205 (191)
     // (re-swept at the end of the round: Cornell box 8 / 12 / 16 / 20 / 24 / 32 -> 1957 / 2033 / 2066 / 2074 / 2078 / 2070)
     p->suspend_lanes = ctx->suspend_lanes >= 0 ? ctx->suspend_lanes : 24;
+    // a phase of a while-while round ends early when at most this many lanes are still in it and some lane has left it
+    // (Trav::round).  1080p, node_min / leaf_min (profiles/r04/c_*): tree in LDS (Cornell box) 0/0 2436, 3/4 2589, 4/8 2590, 8/4 2506
+    // Msamples/s; 4-wide nodes from global memory 0/0 839 | 294, 4/4 1012 | 367, 6/4 1028 | 373, 8/8 1031 | 371 (MESH-100k | MESH-1M)
+    p->node_min_lanes = ctx->node_min_lanes >= 0 ? ctx->node_min_lanes : (p->node_mode == kNodesLds ? 3 : 6);
+    p->leaf_min_lanes = ctx->leaf_min_lanes >= 0 ? ctx->leaf_min_lanes : 4;
 }
 
 int check_ready(pt_context* ctx, const pt_camera* cam) {
@@ -1409,6 +1416,20 @@ void pt_camera_init(pt_camera* c, float fov, float yaw, float pitch, const float
     c->eye.s[1] = 500.0f + shift[1];
     c->eye.s[2] = -1299.037842f + shift[2];
     for (int i = 0; i < 3; ++i) { c->up.s[i] = up[i]; c->right.s[i] = right[i]; c->lookat.s[i] = c->eye.s[i] + ahead[i]; }
+}
+
+// The side effect of the reference's Camera(): main.cpp:334-336 adds this frame's movement along the ROTATED unit axes into
+// global_shift before the eye is placed (the key handlers of main.cpp:1189-1209 set global_forward / rightward / upward to
+// speed * dt or 0).  Same rotations as pt_camera_init, float arithmetic in the reference's order, no fused operations.
+void pt_camera_move(float shift[3], float yaw, float pitch, float forward, float rightward, float upward) {
+    float up[3] = {0.0f, 1.0f, 0.0f}, right[3] = {1.0f, 0.0f, 0.0f}, ahead[3] = {0.0f, 0.0f, 1.0f};
+    rotate_x_ref(up, pitch); rotate_y_ref(up, yaw);
+    rotate_x_ref(right, pitch); rotate_y_ref(right, yaw);
+    rotate_x_ref(ahead, pitch); rotate_y_ref(ahead, yaw);
+    for (int i = 0; i < 3; ++i) {
+        const float a = ahead[i] * forward, r = right[i] * rightward, u = up[i] * upward;
+        shift[i] = ((shift[i] + a) + r) + u;
+    }
 }
 
 int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int32_t world, int32_t rows_per_block, pt_context** out) {
@@ -1927,6 +1948,15 @@ int pt_upload_seeds(pt_context* ctx, const int32_t* seeds, int64_t n) {
 
 static int ptamd_resident_waves(const pt_context*, const LaunchConfig& lc) { return lc.persistent_blocks * (lc.block / 64); }
 
+// Samples per (pass, tile) work item of a persistent launch, by tiles per resident wave (0: whole tiles).
+// fewer tiles per resident wave (1080p over 2 / 4 / 8 GPUs: 4.0 / 2.0 / 1.0): suspend with passes of 16, lockstep with
+// passes of 8, lockstep with whole tiles (profiles/r02/q_*: 95.7 % / 87.5 % / 61.8 % of the one-GPU rate per GPU)
+static int auto_chunk_spp(int n_tiles, int resident_waves, int nsamples) {
+    return n_tiles >= 5 * resident_waves ? (nsamples >= 256 ? 64 : 32)
+         : n_tiles >= 3 * resident_waves ? 16
+         : n_tiles > resident_waves + resident_waves / 4 ? 8 : 0;
+}
+
 static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc) {
     // whole tree in LDS: two 768-thread workgroups per CU (six waves per SIMD) if their LDS fits, else two of 512
     // -- and if the launch has a tile for each of their waves: with fewer (a 1080p frame over 8 GPUs: 4,050 tiles for
@@ -2069,11 +2099,7 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         // 8 / 16 / 32 / 64 -> 1689 / 1760 / 1787 / 1761 Msamples/s; 256 spp: 1706 / 1789 / 1843 / 1868
         // (profiles/r02/n_*; the lockstep kernel of round 1 peaked at 8).
         const int resident_waves = ptamd_resident_waves(ctx, lc);
-        // fewer tiles per resident wave (1080p over 2 / 4 / 8 GPUs: 4.0 / 2.0 / 1.0): suspend with passes of 16, lockstep with
-        // passes of 8, lockstep with whole tiles (profiles/r02/q_*: 95.7 % / 87.5 % / 61.8 % of the one-GPU rate per GPU)
-        const int auto_chunk = p.n_tiles >= 5 * resident_waves ? (nsamples >= 256 ? 64 : 32)
-                             : p.n_tiles >= 3 * resident_waves ? 16
-                             : p.n_tiles > resident_waves + resident_waves / 4 ? 8 : 0;
+        const int auto_chunk = auto_chunk_spp(p.n_tiles, resident_waves, nsamples);
         const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk;
         // work items are numbered with an int on the device: passes x tiles + one failed fetch per resident wave
         const int64_t items = chunk > 0 ? ((int64_t)nsamples + chunk - 1) / chunk * p.n_tiles : p.n_tiles;
@@ -2138,6 +2164,12 @@ int pt_frame_size(const pt_context* ctx, int32_t* width, int32_t* height, int64_
 }
 
 // ---- frame assembly over RCCL (pt_comm.hip)
+int pt_comm_available(void) {
+    std::string err;
+    const int rc = comm_available(&err);
+    return rc == PT_OK ? rc : fail(nullptr, rc, err);
+}
+
 int pt_comm_unique_id(void* id128) {
     if (!id128) return PT_EINVAL;
     std::string err;
@@ -2324,6 +2356,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 32) return fail(ctx, PT_EINVAL, "flat_list: 0..32 big triangles tested before the tree (a 32-bit candidate mask per lane)");
         ctx->flat_list = (int)value;
         ctx->tris_uploaded = false;
+    } else if (k == "node_min_lanes" || k == "leaf_min_lanes") {
+        if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, k + ": -1 default, 0..63");
+        (k == "node_min_lanes" ? ctx->node_min_lanes : ctx->leaf_min_lanes) = (int)value;
     } else if (k == "suspend_lanes") {
         if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, "suspend_lanes: -1 default, 0..63");
         ctx->suspend_lanes = (int)value;
@@ -2535,6 +2570,35 @@ int pt_debug_scene_copy(const pt_context* ctx, pt_triangle* tris, pt_material* m
 
 // counting launches (option count_work): per 8x8 tile of the local frame, the shader-clock cycles / 64 its wave(s) spent on it,
 // summed over the work items of the last pt_render call -- the latency a launch with one tile per wave ends on
+// What pt_render(nsamples) would launch on a device of `cu_count` compute units (0: the context's own): works on a host-only
+// context too, so that the launch policy -- which kernel instance, which schedule, which pass length a rank of an N-GPU job gets
+// -- can be pinned by CPU tests.  out[8] = { threads per workgroup, waves per SIMD, schedule (0 lockstep, 1 suspend), samples per
+// (pass, tile) work item (0: whole tiles), resident waves, tiles, node mode, dynamic LDS bytes }.
+int pt_debug_launch_plan(pt_context* ctx, int32_t nsamples, int32_t cu_count, int64_t out[8]) {
+    if (!ctx || !out || nsamples < 1 || cu_count < 0) return PT_EINVAL;
+    if (!ctx->tris_uploaded) return fail(ctx, PT_EINVAL, "upload_Triangles first");
+    pt_camera cam;
+    const float shift[3] = {0.f, 0.f, 0.f};
+    pt_camera_init(&cam, 60.0f, 0.0f, 0.0f, shift, ctx->W, ctx->H);
+    RenderParams p;
+    fill_params(ctx, &cam, &p);
+    p.nsamples = nsamples;
+    const int saved_cu = ctx->cu_count;
+    const size_t saved_lds = ctx->last_lds_bytes;
+    const int saved_wps = ctx->last_waves_per_simd;
+    if (cu_count > 0) ctx->cu_count = cu_count;
+    LaunchConfig lc;
+    launch_cfg(ctx, p, &lc);
+    const int resident = ptamd_resident_waves(ctx, lc);
+    ctx->cu_count = saved_cu;
+    ctx->last_lds_bytes = saved_lds;
+    ctx->last_waves_per_simd = saved_wps;
+    const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk_spp(p.n_tiles, resident, nsamples);
+    out[0] = lc.block; out[1] = lc.waves_per_simd; out[2] = lc.schedule; out[3] = (chunk > 0 && nsamples > chunk) ? chunk : 0;
+    out[4] = resident; out[5] = p.n_tiles; out[6] = p.node_mode; out[7] = (int64_t)lc.lds_bytes;
+    return PT_OK;
+}
+
 int pt_debug_tile_cost(pt_context* ctx, uint32_t* out, int64_t n) {
     PT_NEED_DEVICE(ctx);
     const int64_t n_tiles = (int64_t)((ctx->W + 7) / 8) * ((ctx->local_rows + 7) / 8);

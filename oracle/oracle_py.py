@@ -40,7 +40,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    so = os.path.join(_HERE, "libpt_oracle.so")
+    so = os.environ.get("PT_ORACLE_LIB") or os.path.join(_HERE, "libpt_oracle.so")     # (bench.py's cpu_baseline: the -march=native build)
     if not os.path.exists(so):
         build()
     L = C.CDLL(so)
@@ -62,6 +62,7 @@ def lib():
     sig("orc_material_make", None, vp, fp, fp, fp, fp, fp, f32, i32)
     sig("orc_triangle_make", None, vp, fp, fp, fp, i32)
     sig("orc_camera_make", None, vp, f32, f32, f32, fp, i32, i32)
+    sig("orc_camera_move", None, fp, f32, f32, f32, f32, f32)
     sig("orc_obj_vertex", None, fp, fp, fp, fp, f32, f32)
     sig("orc_scene_create", vp)
     sig("orc_scene_destroy", None, vp)
@@ -132,6 +133,14 @@ def make_triangle(r1, r2, r3, mati):
     t = np.zeros(1, dtype=TRIANGLE)
     lib().orc_triangle_make(_ptr(t), _f3(r1), _f3(r2), _f3(r3), int(mati))
     return t
+
+
+def camera_move(shift, yaw, pitch, forward, rightward, upward):
+    """Camera()'s side effect on global_shift, main.cpp:334-336; returns the new shift."""
+    import ctypes as C
+    v = (C.c_float * 3)(*[float(x) for x in shift])
+    lib().orc_camera_move(v, float(yaw), float(pitch), float(forward), float(rightward), float(upward))
+    return (v[0], v[1], v[2])
 
 
 def make_camera(fov, yaw, pitch, shift, width, height):

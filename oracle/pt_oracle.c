@@ -252,6 +252,22 @@ void orc_camera_make(orc_camera* c, float fov, float yaw, float pitch, const flo
     c->lookat.x = c->eye.x + ahead[0]; c->lookat.y = c->eye.y + ahead[1]; c->lookat.z = c->eye.z + ahead[2];
 }
 
+/* Camera()'s side effect, main.cpp:323-336: the unit axes rotated by pitch then yaw, and
+ *   global_shift.s[i] = global_shift.s[i] + ahead.s[i]*global_forward + right.s[i]*global_rightward + up.s[i]*global_upward;
+ * (float, left to right; x86-64 g++ emits no fma) -- applied to `shift` in place. */
+void orc_camera_move(float shift[3], float yaw, float pitch, float forward, float rightward, float upward) {
+    float up[3] = { 0.0f, 1.0f, 0.0f }, right[3] = { 1.0f, 0.0f, 0.0f }, ahead[3] = { 0.0f, 0.0f, 1.0f };
+    rot_x(up, pitch); rot_y(up, yaw);
+    rot_x(right, pitch); rot_y(right, yaw);
+    rot_x(ahead, pitch); rot_y(ahead, yaw);
+    for (int i = 0; i < 3; ++i) {
+        volatile float t = ahead[i] * forward;          /* volatile: each product and sum rounded to float on its own */
+        volatile float acc = shift[i] + t;
+        t = right[i] * rightward; acc = acc + t;
+        t = up[i] * upward; acc = acc + t;
+        shift[i] = acc;
+    }
+}
 
 /* Scene::add_Obj's per-vertex transform, main.cpp:598-606: negate x, rotate_x(pitch),
  * rotate_y(yaw), then v*scale+pos (float multiply then add: x86-64 g++, no fma). */

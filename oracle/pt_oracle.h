@@ -79,6 +79,7 @@ void orc_material_make(orc_material* m, const float kd[3], const float ks[3], co
 void orc_triangle_make(orc_triangle* t, const float r1[3], const float r2[3], const float r3[3], int mati); /* main.cpp:144-166 */
 void orc_camera_make(orc_camera* c, float fov, float yaw, float pitch, const float shift[3],
                      int width, int height);                                           /* main.cpp:311-347 */
+void orc_camera_move(float shift[3], float yaw, float pitch, float forward, float rightward, float upward);   /* main.cpp:323-336 */
 
 void orc_obj_vertex(float out[3], const float v[3], const float pos[3], const float scale[3],
                     float pitch, float yaw);                                         /* main.cpp:598-606 */

@@ -70,3 +70,67 @@ def test_tilemap_matches_reference_partition():
     assert np.array_equal(np.sort(allids), np.arange(1920 * 1080))
     idx = t.gather_index("cpu").numpy()
     assert (idx[idx < 1920 * 1080].size == 1920 * 1080) and idx.max() == 1920 * 1080
+
+
+def test_band_context_is_a_one_rank_view_of_the_frame(tmp_path):
+    """bench.py's self-validation (`frame_matches_n1`): a band of 24 rows as the tiling arguments of a ONE-rank context --
+    the C ABI's own pixel map for those arguments must be exactly the band's global pixel ids, for frames whose height is
+    and is not a multiple of the band."""
+    sys.path.insert(0, ROOT)
+    from opencl_path_tracer_amd import api
+    from opencl_path_tracer_amd.distributed import band_context, band_pixel_ids, frame_matches_band
+    for W, H in ((48, 1080), (40, 100), (16, 24), (8, 5)):
+        band = band_context(H, 24)
+        ids = band_pixel_ids(W, H, band)
+        ctx = api.Scene(W, H, device=None, **band)
+        assert np.array_equal(ctx.local_pixel_ids().astype(np.int64), ids)
+        r0 = band["rank"] * band["rows_per_block"]
+        assert ids[0] == r0 * W and ids.size == W * min(band["rows_per_block"], H - r0) and ids.size > 0
+    # the comparison itself: bits, not values (a -0.0 is not a +0.0), RGB only
+    frame = np.random.RandomState(1).rand(40 * 100, 4).astype(np.float32)
+    band = band_context(100, 24)
+    ids = band_pixel_ids(40, 100, band)
+    good = frame[ids].copy()
+    good[:, 3] = 7.0                                     # the pad lane is not part of the contract
+    assert frame_matches_band(frame, good, ids)
+    bad = good.copy()
+    bad[5, 1] = np.nextafter(bad[5, 1], np.float32(2.0))
+    assert not frame_matches_band(frame, bad, ids)
+    frame[ids[3], 0] = 0.0
+    neg = frame[ids].copy()
+    neg[3, 0] = -0.0
+    assert not frame_matches_band(frame, neg, ids)
+
+
+def test_assembled_frame_matches_a_one_rank_band(tmp_path):
+    """The N-rank path end to end over gloo with the check bench.py prints as `frame_matches_n1`: every rank's assembled frame
+    passes the band comparison against a one-rank render of the band's rows (the oracle here), and a frame with one wrong
+    row fails it."""
+    world, W, H, rb = 2, 24, 40, 8
+    mp.spawn(_worker, args=(world, _free_port(), W, H, rb, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from opencl_path_tracer_amd.distributed import band_context, band_pixel_ids, frame_matches_band
+    full = np.load(tmp_path / "full.npy")
+    band = band_context(H, 24)
+    ids = band_pixel_ids(W, H, band)
+    one_rank = full[ids]
+    for r in range(world):
+        got = np.load(tmp_path / ("frame_%d.npy" % r))
+        assert frame_matches_band(got, one_rank, ids)
+        got[ids[W * 9 + 2], 2] += 1.0
+        assert not frame_matches_band(got, one_rank, ids)
+
+
+def test_watchdog_turns_a_missing_rank_into_an_exit_code():
+    """A phase that waits for a rank that never comes must end the process with a non-zero code (bench.py wraps every
+    rendezvous / collective / synchronize in this), and a phase that finishes in time must not be disturbed."""
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from opencl_path_tracer_amd.distributed import Watchdog\n"
+            "with Watchdog(5.0, 'quick phase', 1):\n    time.sleep(0.05)\n"
+            "with Watchdog(0.3, 'all-gather with a missing rank', 1):\n    time.sleep(30)\n"
+            "print('not reached')\n" % ROOT)
+    t0 = __import__("time").time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "not reached" not in r.stdout and "all-gather with a missing rank" in r.stderr
+    assert __import__("time").time() - t0 < 25

@@ -254,3 +254,54 @@ def test_tiling_partitions_the_frame(api, H, world, rb):
         rows = np.unique(ids // W)
         assert ((rows // rb) % world == r).all()
     assert (owner >= 0).all()
+
+
+def test_camera_movement_accumulates_like_the_reference(api, oracle):
+    """main.cpp:334-336: every Camera() adds this frame's movement along the ROTATED unit axes into global_shift before the eye is
+    placed; main.cpp:1189-1209 set global_forward / rightward / upward to +-speed * dt or 0.  Three frames of key presses (W, then
+    W + D, then Q with a new yaw) replayed through pt_camera_move + pt_camera_init against the oracle's restatement: the shift and
+    the 80 camera bytes agree bit for bit after every step, and a frame without movement leaves the shift alone."""
+    fov, W, H = 75.0, 192, 108
+    shift_p = shift_o = (265.055481, 162.305969, 360.414001)             # main.cpp:39
+    steps = [(-63.800002, 15.599997, 1000.0 * 0.016, 0.0, 0.0),           # W for one 16-ms frame
+             (-63.800002, 15.599997, 1000.0 * 0.021, 1000.0 * 0.021, 0.0),   # W + D
+             (-20.0, 15.599997, 0.0, 0.0, 1000.0 * 0.033),                # Q after the mouse turned the view
+             (-20.0, 15.599997, 0.0, 0.0, 0.0)]                           # keys released
+    for yaw, pitch, fwd, rgt, upw in steps:
+        before = shift_p
+        shift_p = api.camera_move(shift_p, yaw, pitch, fwd, rgt, upw)
+        shift_o = oracle.camera_move(shift_o, yaw, pitch, fwd, rgt, upw)
+        assert np.array_equal(np.float32(shift_p).view(np.uint32), np.float32(shift_o).view(np.uint32))
+        cam_p = api.Camera(fov, yaw, pitch, shift_p, W, H)
+        cam_o = oracle.make_camera(fov, yaw, pitch, shift_o, W, H)
+        assert cam_p.tobytes() == cam_o.tobytes()
+        if fwd == rgt == upw == 0.0:
+            assert shift_p == before
+        else:
+            assert shift_p != before
+    # the movement is along the view: forward at yaw 0 / pitch 0 is +z only
+    assert api.camera_move((0.0, 0.0, 0.0), 0.0, 0.0, 5.0, 0.0, 0.0) == (0.0, 0.0, 5.0)
+    assert api.camera_move((1.0, 2.0, 3.0), 0.0, 0.0, 0.0, 2.0, -1.0) == (3.0, 1.0, 3.0)
+
+
+def test_launch_plan_of_a_rank_of_eight(api, cb_spec):
+    """The launch policy DESIGN.md section 6 states, pinned: on a 256-CU device a one-GPU 1080p Cornell frame takes the six-wave
+    768-thread instance under the suspend schedule with passes of 32 samples (64 from 256 spp per launch); the rank of an 8-GPU job
+    has 4,050 tiles for the 6,144 waves that instance would keep resident, so it gets the 512-thread instance, lockstep, whole
+    tiles -- the measured-best shape for one tile per wave (profiles/r03/g_*); ranks of 2 / 4 keep the wide instance in lockstep
+    with passes of 8, and so does a rank of a 4K frame over 8 (16,320 tiles)."""
+    def plan(W, H, rank, world, nsamples=64):
+        sc = api.Scene(W, H, device=None, rank=rank, world=world, rows_per_block=8).load(cb_spec)
+        return sc.debug_launch_plan(nsamples, 256)
+    one = plan(1920, 1080, 0, 1)
+    assert (one["block"], one["waves_per_simd"], one["schedule"], one["chunk_spp"]) == (768, 6, 1, 32) and one["tiles"] == 32400 and one["resident_waves"] == 6144
+    assert plan(1920, 1080, 0, 1, 256)["chunk_spp"] == 64
+    for r in (0, 3, 7):
+        p8 = plan(1920, 1080, r, 8)
+        assert (p8["block"], p8["waves_per_simd"], p8["schedule"], p8["chunk_spp"]) == (512, 4, 0, 0), p8
+        assert 3840 <= p8["tiles"] <= 4080 and p8["resident_waves"] == 4096 and p8["node_mode"] == 0
+    p2, p4 = plan(1920, 1080, 1, 2), plan(1920, 1080, 2, 4)
+    assert (p2["block"], p2["schedule"], p2["chunk_spp"]) == (768, 0, 8), p2
+    assert (p4["block"], p4["schedule"], p4["chunk_spp"]) == (768, 0, 8), p4
+    k8 = plan(3840, 2160, 5, 8)             # 16,320 tiles: 2.7 per resident wave
+    assert (k8["block"], k8["waves_per_simd"], k8["schedule"], k8["chunk_spp"]) == (768, 6, 0, 8), k8

@@ -53,6 +53,28 @@
 #define OP_CMPCND2(i) "v_cmp_lt_f32 vcc, %" #i ", %9\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\nv_cndmask_b32 v20, v20, %8, vcc\n"
 #define OP_CMPCND64(i) "v_cmp_lt_f32_e64 s[10:11], %" #i ", %9\nv_cndmask_b32_e64 %" #i ", %" #i ", %8, s[10:11]\n"
 
+#define OP_CVTUB(i) "v_cvt_f32_ubyte1_e32 %" #i ", %" #i "\n"
+#define OP_MIXLO(i) "v_fma_mix_f32 %" #i ", %" #i ", %8, %9 op_sel_hi:[1,0,0]\n"
+#define OP_MIXHI(i) "v_fma_mix_f32 %" #i ", %" #i ", %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+#define OP_ANDOR(i) "v_and_or_b32 %" #i ", %" #i ", %8, %9\n"
+#define OP_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 8, 8\n"
+#define OP_PERM(i) "v_perm_b32 %" #i ", %" #i ", %8, %9\n"
+#define OP_MINU(i) "v_min_u32 %" #i ", %" #i ", %9\n"
+#define OP_MED3U(i) "v_med3_u32 %" #i ", %" #i ", %8, %9\n"
+#define OP_MIN3U(i) "v_min3_u32 %" #i ", %" #i ", %8, %9\n"
+#define OP_LDEXP(i) "v_ldexp_f32 %" #i ", %" #i ", %9\n"
+#define OP_LSHSDWA(i) "v_lshlrev_b32_sdwa %" #i ", %9, %" #i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define OP_CVTF16(i) "v_cvt_f32_f16 %" #i ", %" #i "\n"
+#define OP_MAX3(i) "v_max3_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_LSHLOR(i) "v_lshl_or_b32 %" #i ", %" #i ", 8, %9\n"
+#define OP_CMPU(i) "v_cmp_lt_u32 vcc, %" #i ", %9\n"
+#define OP_CMPADDC(i) "v_cmp_lt_f32 vcc, %" #i ", %9\nv_addc_co_u32 v20, vcc, 0, v20, vcc\n"
+#define OP_SANDCND(i) "v_cmp_lt_f32 vcc, %" #i ", %9\ns_and_b64 vcc, vcc, s[10:11]\nv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define OP_SANDCND64(i) "v_cmp_lt_f32 vcc, %" #i ", %9\ns_and_b64 s[10:11], vcc, s[10:11]\nv_cndmask_b32_e64 %" #i ", %" #i ", %8, s[10:11]\n"
+#define OP_CVTU32(i) "v_cvt_f32_u32 %" #i ", %" #i "\n"
+#define OP_PKFMAF16(i) "v_pk_fma_f16 %" #i ", %" #i ", %8, %9\n"
+#define OP_DSW(i) "ds_write_b32 %8, %" #i "\n"
+
 template <int OP>
 __global__ void __launch_bounds__(256) k(unsigned long long mask, int iters, float* out) {
     const unsigned lane = threadIdx.x & 63;
@@ -105,6 +127,26 @@ __global__ void __launch_bounds__(256) k(unsigned long long mask, int iters, flo
                 if (OP == 40) CHAIN8(OP_CMPGAP);
                 if (OP == 41) CHAIN8(OP_SMOVCND);
                 if (OP == 42) CHAIN8(OP_CMPCND2);
+                if (OP == 43) CHAIN8(OP_CVTUB);
+                if (OP == 44) CHAIN8(OP_MIXLO);
+                if (OP == 45) CHAIN8(OP_MIXHI);
+                if (OP == 46) CHAIN8(OP_ANDOR);
+                if (OP == 47) CHAIN8(OP_BFE);
+                if (OP == 48) CHAIN8(OP_PERM);
+                if (OP == 49) CHAIN8(OP_MINU);
+                if (OP == 50) CHAIN8(OP_MED3U);
+                if (OP == 51) CHAIN8(OP_MIN3U);
+                if (OP == 52) CHAIN8(OP_LDEXP);
+                if (OP == 53) CHAIN8(OP_LSHSDWA);
+                if (OP == 54) CHAIN8(OP_CVTF16);
+                if (OP == 55) CHAIN8(OP_MAX3);
+                if (OP == 56) CHAIN8(OP_LSHLOR);
+                if (OP == 57) CHAIN8(OP_CMPU);
+                if (OP == 58) CHAIN8(OP_CMPADDC);
+                if (OP == 59) CHAIN8(OP_SANDCND);
+                if (OP == 60) CHAIN8(OP_SANDCND64);
+                if (OP == 61) CHAIN8(OP_CVTU32);
+                if (OP == 62) CHAIN8(OP_PKFMAF16);
             }
         }
     }
@@ -133,6 +175,47 @@ void run(const char* name, float* o) {
     printf("\n");
 }
 
+template <int OP>
+void run_masks(const char* name, float* o) {      // the same instruction stream under differently PLACED sets of active lanes
+    const int blocks = 256 * 16, iters = 1000;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const unsigned long long ms_[] = {0xffull, 0xff00000000000000ull, 0x0101010101010101ull, 0x000f000f000f000full, 0x1ffull, 0x0101010101010103ull,
+                                      0xffffull, 0x1111111111111111ull, 0x00ff00ff00000000ull, 0xffffffffull, 0xffffffff00000000ull, 0x5555555555555555ull};
+    printf("%-14s", name);
+    for (unsigned long long mk : ms_) {
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, mk, iters, o);
+            hipEventRecord(b); hipEventSynchronize(b);
+            hipEventElapsedTime(&ms, a, b);
+        }
+        const double insts_per_simd = (double)blocks * 4 / 1024 * iters * 64;
+        printf(" %6.2f", ms * 1e-3 * 2.4e9 / insts_per_simd);
+    }
+    printf("\n");
+}
+
+template <int OP>
+void run_occ(const char* name, float* o) {      // waves per SIMD 1 / 2 / 4 / 8, 8 active lanes against 64: a per-wave issue interval or SIMD time?
+    const int iters = 1000;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    printf("%-14s", name);
+    for (unsigned long long mk : {0xffull, ~0ull})
+        for (int wps : {1, 2, 4, 8}) {
+            const int blocks = 256 * wps;
+            float ms = 0;
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(a);
+                hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, mk, iters, o);
+                hipEventRecord(b); hipEventSynchronize(b);
+                hipEventElapsedTime(&ms, a, b);
+            }
+            printf(" %6.2f", ms * 1e-3 * 2.4e9 / ((double)iters * 64));      // clocks per instruction of ONE wave's stream
+        }
+    printf("\n");
+}
+
 int main() {
     float* o; hipMalloc(&o, 256 * 16 * 256 * sizeof(float));
     printf("clocks (at 2.4 GHz) per wave instruction per SIMD; columns = active lanes\n%-14s %6d %6d %6d %6d %6d %6d %6d %6d\n", "op", 64, 33, 32, 17, 16, 9, 8, 1);
@@ -146,5 +229,11 @@ int main() {
     run<34>("v_mad_u64_u32", o); run<35>("cndmask indep", o);
     run<36>("cndmask e64 vcc", o); run<37>("cndmask sdwa", o); run<38>("cmp+cnd vcc x2", o); run<39>("cmp+cnd sgpr x2", o);
     run<40>("cmp,add,add,cnd", o); run<41>("s_mov vcc+cnd", o); run<42>("cmp,cnd,cnd", o);
+    run<43>("v_cvt_f32_ubyte", o); run<44>("fma_mix lo", o); run<45>("fma_mix hi", o); run<46>("v_and_or_b32", o); run<47>("v_bfe_u32", o); run<48>("v_perm_b32", o); run<49>("v_min_u32", o); run<50>("v_med3_u32", o); run<51>("v_min3_u32", o); run<52>("v_ldexp_f32", o); run<53>("lshl sdwa byte", o); run<54>("v_cvt_f32_f16", o); run<55>("v_max3_f32", o); run<56>("v_lshl_or_b32", o); run<57>("v_cmp_lt_u32", o); run<58>("cmp+addc x2", o); run<59>("cmp,s_and,cnd x2", o); run<60>("cmp,s_and,cnd64", o); run<61>("v_cvt_f32_u32", o); run<62>("v_pk_fma_f16", o);
+    printf("\nthe same under placed lane sets: 8 low | 8 high | 8 spread (1 per 8) | 4x4 spread | 9 low | 9 spread | 16 low | 16 spread (1 per 4) | 16 in upper half | 32 low | 32 high | 32 alternate\n");
+    run_masks<0>("v_fma_f32", o); run_masks<3>("v_max_f32", o); run_masks<4>("v_cmp_lt_f32", o); run_masks<14>("cndmask sgpr", o); run_masks<43>("v_cvt_f32_ubyte", o);
+    run_masks<19>("v_med3_f32", o); run_masks<44>("fma_mix lo", o); run_masks<2>("v_add_f32", o); run_masks<10>("v_rcp_f32", o);
+    printf("\nclocks per instruction of one wave's stream (elapsed / instructions per wave); columns: 8 active lanes at 1 / 2 / 4 / 8 waves per SIMD, then 64 active lanes at 1 / 2 / 4 / 8\n");
+    run_occ<0>("v_fma_f32", o); run_occ<3>("v_max_f32", o); run_occ<4>("v_cmp_lt_f32", o); run_occ<14>("cndmask sgpr", o); run_occ<2>("v_add_f32", o); run_occ<10>("v_rcp_f32", o);
     return 0;
 }
