@@ -95,10 +95,13 @@ struct pt_context {
     float4* d_ldr = nullptr;
     unsigned long long* d_stats = nullptr;
     // wavefront variant: path state + queues (allocated on first use)
-    float4* d_wf_state = nullptr;   // per local pixel: 4 float4 worth of path factors + colour (5 x 12 B), 8 float4 of ray streams, 2 float2 of hits
+    float4* d_wf_state = nullptr;   // per local pixel: 4 float4 worth of path factors + colour (5 x 12 B), 8 + 4 float4 of ray streams (rsA, rsB; rsC), 2 float2 of hits
     int32_t* d_wf_queues = nullptr; // 3 x npix int32 (class queues)
     std::vector<float> cost_boxes;  // 6 floats per complex object (wavefront cost classes)
-    uint32_t* d_wf_counters = nullptr;
+    uint32_t* d_wf_counters = nullptr;   // kWfMaxChains x (kWfMaxBounces + 4) rows
+    hipStream_t wf_stream[kWfMaxChains] = {};   // chains 1.. of the wavefront variant (chain 0 runs on `stream`)
+    hipEvent_t wf_event[kWfMaxChains] = {};
+    int wf_streams = -1;                 // option wf_streams: chains of the wavefront variant (-1: kWfDefaultChains)
     bool own_rnds = true, own_colors = true;
     hipStream_t stream = nullptr;
 
@@ -1228,7 +1231,9 @@ int alloc_stack_overflow(pt_context* ctx) {
     const int extra = ctx->nodes4.empty() ? 0 : wide_stack_entries(ctx->wide_pending) - ctx->wide_lds_entries;
     if (extra <= 0) return PT_OK;
     const size_t n_tiles = (size_t)((ctx->W + 7) / 8) * (size_t)((ctx->local_rows + 7) / 8);
-    const size_t lanes = 256 * std::max<size_t>((size_t)ctx->cu_count * 16, (n_tiles + 3) / 4);
+    // every grid that can be in flight at once: k_render (one thread per pixel at most), or kWfDefaultChains concurrent wf_intersect
+    // launches of the wavefront variant (2 cost classes x 6 x 256 threads per CU each, render_wavefront)
+    const size_t lanes = 256 * std::max<size_t>((size_t)ctx->cu_count * 12 * kWfDefaultChains, (n_tiles + 3) / 4);
     PT_HIP(ctx, hipMalloc((void**)&ctx->d_stack_ovf, lanes * (size_t)extra * sizeof(uint32_t)));
     ctx->stack_ovf_lanes = lanes;
     return PT_OK;
@@ -1522,6 +1527,10 @@ void pt_destroy(pt_context* ctx) {
         if (ctx->d_wf_state) (void)hipFree(ctx->d_wf_state);
         if (ctx->d_wf_queues) (void)hipFree(ctx->d_wf_queues);
         if (ctx->d_wf_counters) (void)hipFree(ctx->d_wf_counters);
+        for (int c = 0; c < kWfMaxChains; ++c) {
+            if (ctx->wf_stream[c]) (void)hipStreamDestroy(ctx->wf_stream[c]);
+            if (ctx->wf_event[c]) (void)hipEventDestroy(ctx->wf_event[c]);
+        }
         if (ctx->comm) comm_destroy(ctx->comm);
         if (ctx->d_gathered) (void)hipFree(ctx->d_gathered);
         if (ctx->d_frame) (void)hipFree(ctx->d_frame);
@@ -2024,47 +2033,90 @@ int pt_trace_rays(pt_context* ctx, const pt_camera* cam, int32_t iterations, int
     return time_end(ctx, ep);
 }
 
+// The stream-compacted variant.  The local pixels are cut into `wf_streams` contiguous chains; every chain owns its ray streams,
+// hit stream, class queues and counters and runs its passes -- wf_generate, then per bounce wf_intersect and wf_shade -- on a HIP
+// stream of its own.  A pass is a chain of 17 dependent launches of ~100 us, and a persistent wf_intersect launch ends on its
+// longest ray: ~60 us of the 133 us a 1080p launch took were the same at a quarter and at four times the rays
+// (profiles/r04/).  With two chains the tail of one runs under the body of the other.
 static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsamples) {
     if (rp.iterations > kWfMaxBounces) return fail(ctx, PT_EINVAL, "wavefront variant supports at most 1023 iterations");
     const size_t np = (size_t)std::max<int64_t>(ctx->npix, 1);
+    constexpr size_t kCounterWords = (size_t)kWfCounterStride * (kWfMaxBounces + 4);
     if (!ctx->d_wf_state) {
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_state, sizeof(float4) * 13 * np));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_state, sizeof(float4) * 17 * np));
         PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_queues, sizeof(int32_t) * 3 * np));
-        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_counters, sizeof(uint32_t) * kWfCounterStride * (kWfMaxBounces + 4)));
+        PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_counters, sizeof(uint32_t) * kCounterWords * kWfMaxChains));
     }
-    WfParams w;
-    w.rp = rp;
-    w.sP = reinterpret_cast<float*>(ctx->d_wf_state);        // kWfFields x np x 12 B <= 4 x np x 16 B
-    for (int par = 0; par < 2; ++par)
-        for (int c = 0; c < 2; ++c) {
-            w.rsA[par][c] = ctx->d_wf_state + (size_t)(4 + (par * 2 + c) * 2 + 0) * np;
-            w.rsB[par][c] = ctx->d_wf_state + (size_t)(4 + (par * 2 + c) * 2 + 1) * np;
-        }
-    w.hit[0] = reinterpret_cast<float2*>(ctx->d_wf_state + 12 * np);
-    w.hit[1] = w.hit[0] + np;
-    w.q_cls[0] = ctx->d_wf_queues + 0 * np; w.q_cls[1] = ctx->d_wf_queues + 1 * np; w.q_cls[2] = ctx->d_wf_queues + 2 * np;
-    w.counters = ctx->d_wf_counters;
-    w.npix = (int32_t)ctx->npix;
-    w.n_cbox = ctx->cost_binning ? (int32_t)(ctx->cost_boxes.size() / 6) : 0;
-    for (int b = 0; b < w.n_cbox; ++b)
-        for (int k = 0; k < 6; ++k) w.cbox[b][k] = ctx->cost_boxes[(size_t)b * 6 + k];
     if (ctx->npix == 0) return PT_OK;
-    for (int32_t k = 0; k < nsamples; ++k) {
-        w.sample = rp.first_sample + k;
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_wf_counters, 0, sizeof(uint32_t) * kWfCounterStride, ctx->stream));
-        PT_HIP(ctx, launch_wf_generate(w, ctx->stream));
-        for (int32_t b = 0; b < rp.iterations; ++b) {
-            EventPair* ep;
-            int rc = time_begin(ctx, &ep);
-            if (rc != PT_OK) return rc;
-            PT_HIP(ctx, launch_wf_intersect(w, b, ctx->cu_count, ctx->stream));
-            if ((rc = time_end(ctx, ep)) != PT_OK) return rc;
-            PT_HIP(ctx, launch_wf_shade(w, b, ctx->stream));
+    // chains of whole 8,192-pixel units, at least ~64k pixels each (a chain of a few thousand rays is all launch overhead)
+    const int want = ctx->wf_streams > 0 ? ctx->wf_streams : kWfDefaultChains;
+    int chains = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, kWfMaxChains), ctx->npix / 65536));
+    // 4-wide traversal: the part of a lane's stack that lies in global memory is addressed by the lane's place in the GRID; chains
+    // run concurrently, so each gets its own range of that buffer (the widest wf_intersect grid: 2 cost classes x 6 x 256 threads per CU)
+    const size_t chain_lanes = (size_t)2 * 6 * 256 * (size_t)ctx->cu_count;
+    if (rp.stack_ovf) chains = (int)std::max<size_t>(1, std::min<size_t>((size_t)chains, (size_t)rp.stack_ovf_lanes / chain_lanes));
+    for (int c = 1; c < chains; ++c)
+        if (!ctx->wf_stream[c]) {
+            PT_HIP(ctx, hipStreamCreateWithFlags(&ctx->wf_stream[c], hipStreamNonBlocking));
+            PT_HIP(ctx, hipEventCreateWithFlags(&ctx->wf_event[c], hipEventDisableTiming));
         }
+    if (!ctx->wf_event[0]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->wf_event[0], hipEventDisableTiming));
+    WfParams w[kWfMaxChains];
+    const int64_t unit = 8192;
+    const int64_t per = ((ctx->npix + chains - 1) / chains + unit - 1) / unit * unit;
+    for (int c = 0; c < chains; ++c) {
+        WfParams& wc = w[c];
+        const int64_t p0 = std::min<int64_t>((int64_t)c * per, ctx->npix), p1 = std::min<int64_t>(p0 + per, ctx->npix);
+        wc.rp = rp;
+        if (rp.stack_ovf) wc.rp.stack_ovf = rp.stack_ovf + (size_t)c * chain_lanes;      // (stack_ovf_lanes stays the stride between entries)
+        wc.sP = reinterpret_cast<float*>(ctx->d_wf_state);        // kWfFields x np x 12 B <= 4 x np x 16 B, indexed by local pixel
+        for (int par = 0; par < 2; ++par)
+            for (int k = 0; k < 2; ++k) {
+                wc.rsA[par][k] = ctx->d_wf_state + (size_t)(4 + (par * 2 + k) * 2 + 0) * np + p0;      // a chain's streams: its slice of each array
+                wc.rsB[par][k] = ctx->d_wf_state + (size_t)(4 + (par * 2 + k) * 2 + 1) * np + p0;
+                wc.rsC[par][k] = ctx->d_wf_state + (size_t)(13 + par * 2 + k) * np + p0;
+            }
+        wc.hit[0] = reinterpret_cast<float2*>(ctx->d_wf_state + 12 * np) + p0;
+        wc.hit[1] = reinterpret_cast<float2*>(ctx->d_wf_state + 12 * np) + np + p0;
+        for (int k = 0; k < 3; ++k) wc.q_cls[k] = ctx->d_wf_queues + (size_t)k * np + p0;
+        wc.counters = ctx->d_wf_counters + (size_t)c * kCounterWords;
+        wc.npix = (int32_t)(p1 - p0);
+        wc.pix0 = (int32_t)p0;
+        wc.npix_all = (int32_t)ctx->npix;
+        wc.n_cbox = ctx->cost_binning ? (int32_t)(ctx->cost_boxes.size() / 6) : 0;
+        for (int b = 0; b < wc.n_cbox; ++b)
+            for (int k = 0; k < 6; ++k) wc.cbox[b][k] = ctx->cost_boxes[(size_t)b * 6 + k];
+    }
+    // the other chains' streams start behind whatever the context's stream holds, and the context's stream ends behind them
+    PT_HIP(ctx, hipEventRecord(ctx->wf_event[0], ctx->stream));
+    for (int c = 1; c < chains; ++c) PT_HIP(ctx, hipStreamWaitEvent(ctx->wf_stream[c], ctx->wf_event[0], 0));
+    for (int32_t k = 0; k < nsamples; ++k) {
+        for (int c = 0; c < chains; ++c) {
+            if (w[c].npix == 0) continue;
+            hipStream_t st = c == 0 ? ctx->stream : ctx->wf_stream[c];
+            w[c].sample = rp.first_sample + k;
+            PT_HIP(ctx, hipMemsetAsync(w[c].counters, 0, sizeof(uint32_t) * kWfCounterStride, st));
+            PT_HIP(ctx, launch_wf_generate(w[c], st));
+        }
+        for (int32_t b = 0; b < rp.iterations; ++b)
+            for (int c = 0; c < chains; ++c) {
+                if (w[c].npix == 0) continue;
+                hipStream_t st = c == 0 ? ctx->stream : ctx->wf_stream[c];
+                EventPair* ep = nullptr;
+                int rc = PT_OK;
+                if (c == 0 && (rc = time_begin(ctx, &ep)) != PT_OK) return rc;      // kernel_ms: wf_intersect of chain 0 (the others overlap it)
+                PT_HIP(ctx, launch_wf_intersect(w[c], b, ctx->cu_count, st));
+                if (c == 0 && (rc = time_end(ctx, ep)) != PT_OK) return rc;
+                PT_HIP(ctx, launch_wf_shade(w[c], b, st));
+            }
         if (ctx->timing && ctx->events_used >= 4096) {   // bound the event pool
             int rc = time_collect(ctx);
             if (rc != PT_OK) return rc;
         }
+    }
+    for (int c = 1; c < chains; ++c) {
+        PT_HIP(ctx, hipEventRecord(ctx->wf_event[c], ctx->wf_stream[c]));
+        PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->wf_event[c], 0));
     }
     return PT_OK;
 }
@@ -2356,6 +2408,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 32) return fail(ctx, PT_EINVAL, "flat_list: 0..32 big triangles tested before the tree (a 32-bit candidate mask per lane)");
         ctx->flat_list = (int)value;
         ctx->tris_uploaded = false;
+    } else if (k == "wf_streams") {
+        if (value < -1 || value == 0 || value > kWfMaxChains) return fail(ctx, PT_EINVAL, "wf_streams: -1 default, 1..8");
+        ctx->wf_streams = (int)value;
     } else if (k == "node_min_lanes" || k == "leaf_min_lanes") {
         if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, k + ": -1 default, 0..63");
         (k == "node_min_lanes" ? ctx->node_min_lanes : ctx->leaf_min_lanes) = (int)value;

@@ -135,12 +135,18 @@ struct RenderParams {
 };
 
 // ---- wavefront (stream-compacted) formulation
-// Per local pixel (index li): the four path factors and the colour, five arrays of 12-B records sP[field][li]
-// (kWfL .. kWfC).  A field is read only if it was written in this sample and written only by the material that changes it
-// (PathInHbm, pt_wavefront.hip); the LCG state stays in rnds[li].
-// Ray streams, one per (bounce parity, cost class), addressed by POSITION (compact, written and
-// read coalesced), 32 B per ray:     rsA = {P.xyz, D.x}  rsB = {D.y, D.z, bits(li), bits(flags)}
-//                                    flags: bit f (f < 5) = field f of sP is valid; bit 5 = the path is inside glass
+// Ray streams, one per (bounce parity, cost class), addressed by POSITION (compact, written and read coalesced), 48 B per
+// ray:   rsA = {P.xyz, D.x}   rsB = {D.y, D.z, bits(li), bits(flags)}   rsC = {factor_L.xyz, bits(LCG state)}
+// What changes at (almost) every segment rides the stream: the ray, factor_L (every diffuse hit multiplies it) and the LCG
+// state (every diffuse / emitter / glass hit draws) -- round 3 kept the last two in per-PIXEL arrays, 12-B and 4-B accesses
+// scattered by the compaction order, which cost a 64-byte sector each way each.  wf_intersect reads rsA and half of rsB only.
+// Per local pixel (index li): the other three factors and the colour, arrays of 12-B records sP[field][li] (kWfB .. kWfC; the
+// kWfL slot is unused).  A field is read only if it was written in this sample and written only by the material that changes it
+// (PathInHbm, pt_wavefront.hip): mirrors factor_S, glass factor_R, emitters the colour; factor_B only where a material has a
+// specular lobe -- with ks = 0 it becomes +0 at the first diffuse hit and stays there, which is one flag bit, not 12 bytes.
+// rnds[li] is read by wf_generate and written when the path ends.
+//                                    flags: bit f (f < 5) = field f of sP is valid; bit 5 = the path is inside glass;
+//                                    bit 6 = factor_B is +0 in all three components (nothing stored)
 // Hit stream, parallel to the ray stream of the current bounce, 8 B:  hit = {t, bits(tri)}
 // Class queues (shade input): entries (cost << 31) | position.
 // Counter rows (kWfCounterStride words each), see wf_row(): 0 n_ray cheap, 1 n_ray expensive,
@@ -152,18 +158,24 @@ constexpr int kWfMaxBounces = 1023;
 constexpr int kWfGenRow = 0;
 __host__ __device__ inline int wf_row(int bounce) { return bounce == 0 ? kWfGenRow : bounce + 1; }
 constexpr int kWfMaxCostBoxes = 8;
-enum : int { kWfL = 0, kWfB = 1, kWfS = 2, kWfR = 3, kWfC = 4, kWfFields = 5, kWfInsideBit = 1 << 5 };
+constexpr int kWfMaxChains = 8;
+constexpr int kWfDefaultChains = 4;
+enum : int { kWfL = 0, kWfB = 1, kWfS = 2, kWfR = 3, kWfC = 4, kWfFields = 5, kWfInsideBit = 1 << 5, kWfBZeroBit = 1 << 6 };
 struct WfParams {
     RenderParams rp;
     float* sP;             // [kWfFields][npix] x 3 floats
     float4* rsA[2][2];     // [bounce parity][cost class]
     float4* rsB[2][2];
+    float4* rsC[2][2];
     float2* hit[2];        // [cost class]
     int32_t* q_cls[3];     // shade input queues: 0 diffuse/emitter, 1 mirror/dielectric/other, 2 miss
     uint32_t* counters;    // [(iterations + 3) * kWfCounterStride]
     float cbox[kWfMaxCostBoxes][6];   // bounding boxes of the complex objects (min xyz, max xyz)
     int32_t n_cbox;
-    int32_t npix;
+    int32_t npix;          // pixels of this CHAIN (the local pixels are cut into wf_streams contiguous chains, each with its own
+                           // streams, queues and counters, run on its own HIP stream: one chain's launch tails under another's work)
+    int32_t pix0;          // first local pixel of the chain
+    int32_t npix_all;      // local pixels of the context (stride of sP's fields)
     int32_t sample;        // current_sample of this pass
 };
 

@@ -17,10 +17,11 @@ namespace ptamd {
 //                 range) while the stragglers carry on.  At the end of its range the block
 //                 compacts its rays into three class queues by the material type they hit
 //                 (order-preserving ballot scan through LDS, 3 global atomics per 1,024 rays).
-//   wf_shade    : one block row per class -> waves are material-coherent.  A hit moves only the part of the path state
-//                 its material touches (PathInHbm): diffuse fL + fB, mirror fS, dielectric fR, an emitter reads what
+//   wf_shade    : one block row per class -> waves are material-coherent.  The ray, factor_L and the LCG state ride the
+//                 position-addressed stream (48 B read + 48 B written per surviving ray, coalesced); per PIXEL a hit moves only
+//                 what its material touches (PathInHbm): mirror fS, dielectric fR, a specular lobe fB, an emitter reads what
 //                 was ever written and adds to the colour.  Survivors go to the next bounce's ray queues; paths that
-//                 end (miss / last bounce) fold their colour into the running mean (prog.cl:379).
+//                 end (miss / last bounce) fold their colour into the running mean (prog.cl:379) and store their LCG state.
 // Ray queues come in two COST classes: a ray that misses the bounding boxes of every complex
 // object (more than 16 triangles) can only hit the few large triangles around them and finishes
 // in a handful of steps; mixing it into a wave with rays that walk a 1,000-triangle object leaves
@@ -94,6 +95,7 @@ struct PathInHbm {
     float* base;         // &sP[0][li]
     size_t fstride;      // floats between fields
     unsigned flags;
+    f3 fL;               // factor_L: rides the ray stream (rsC), not sP
     PT_DEV f3 get(int f, float init) const {
         f3 v = mk(init, init, init);
         if (flags & (1u << f)) {
@@ -109,13 +111,22 @@ struct PathInHbm {
         q[2] = v.z;
         flags |= 1u << f;
     }
-    PT_DEV f3 L() const { return get(kWfL, 1.f); }
-    PT_DEV f3 B() const { return get(kWfB, 1.f); }
+    PT_DEV f3 L() const { return fL; }
+    // factor_B: a value that is +0 in all three components (what ks = 0 makes of it at the first diffuse hit, for good) is a
+    // flag, not a record -- the reader gets the very bits that would have been stored
+    PT_DEV f3 B() const { return (flags & (unsigned)kWfBZeroBit) ? mk(0.f, 0.f, 0.f) : get(kWfB, 1.f); }
     PT_DEV f3 S() const { return get(kWfS, 1.f); }
     PT_DEV f3 R() const { return get(kWfR, 1.f); }
     PT_DEV f3 C() const { return get(kWfC, 0.f); }
-    PT_DEV void setL(f3 v) { put(kWfL, v); }
-    PT_DEV void setB(f3 v) { put(kWfB, v); }
+    PT_DEV void setL(f3 v) { fL = v; }
+    PT_DEV void setB(f3 v) {
+        if ((__float_as_int(v.x) | __float_as_int(v.y) | __float_as_int(v.z)) == 0) {
+            flags = (flags | (unsigned)kWfBZeroBit) & ~(1u << kWfB);
+        } else {
+            flags &= ~(unsigned)kWfBZeroBit;
+            put(kWfB, v);
+        }
+    }
     PT_DEV void setS(f3 v) { put(kWfS, v); }
     PT_DEV void setR(f3 v) { put(kWfR, v); }
     PT_DEV void setC(f3 v) { put(kWfC, v); }
@@ -173,15 +184,18 @@ __global__ void __launch_bounds__(kWfGenBlock) wf_generate(WfParams w) {
     int cost[kWfGenPerThread];
     f3 P[kWfGenPerThread], D[kWfGenPerThread];
     int lis[kWfGenPerThread];
+    int seeds[kWfGenPerThread];
     unsigned live = 0;
 #pragma unroll
     for (int k = 0; k < kWfGenPerThread; ++k) {
-        const int li = (blockIdx.x * kWfGenPerThread + k) * kWfGenBlock + threadIdx.x;
+        const int idx = (blockIdx.x * kWfGenPerThread + k) * kWfGenBlock + threadIdx.x;      // pixel of the chain
+        const int li = w.pix0 + idx;
         lis[k] = li;
         cost[k] = -1;
+        seeds[k] = 0;
         P[k] = mk(0.f, 0.f, 0.f);
         D[k] = mk(0.f, 0.f, 1.f);
-        if (li < w.npix) {
+        if (idx < w.npix) {
             ++live;
             const int lrow = li / p.width, x = li - lrow * p.width;
             const int grow = ((lrow / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (lrow % p.rows_per_block);
@@ -189,9 +203,13 @@ __global__ void __launch_bounds__(kWfGenBlock) wf_generate(WfParams w) {
             int seed = p.rnds[li];
             const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
             camera_get_ray(gid, p.cam, rnd1, rnd2, &P[k], &D[k]);
-            p.rnds[li] = seed;
-            if (p.iterations <= 0) wf_finalize(w, li, mk(0.0f, 0.0f, 0.0f));
-            else cost[k] = ray_cost_class(w, P[k], D[k]);
+            seeds[k] = seed;
+            if (p.iterations <= 0) {
+                wf_finalize(w, li, mk(0.0f, 0.0f, 0.0f));
+                p.rnds[li] = seed;
+            } else {
+                cost[k] = ray_cost_class(w, P[k], D[k]);
+            }
         }
     }
     if (p.stats) {
@@ -205,12 +223,20 @@ __global__ void __launch_bounds__(kWfGenBlock) wf_generate(WfParams w) {
         if (cost[k] >= 0) {
             w.rsA[0][cost[k]][pos[k]] = make_float4(P[k].x, P[k].y, P[k].z, D[k].x);
             w.rsB[0][cost[k]][pos[k]] = make_float4(D[k].y, D[k].z, __int_as_float(lis[k]), 0.0f);
+            w.rsC[0][cost[k]][pos[k]] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(seeds[k]));      // factor_L = 1 (prog.cl:307), LCG state
         }
 }
 
 // Rays per wave: each wave owns a contiguous range of the bounce's ray stream (no global atomics
 // on the fetch side; blocks that finish early are replaced by the dispatcher).
-constexpr int kWfRaysPerWave = 256;
+#ifndef PT_WF_RPW
+#define PT_WF_RPW 256
+#endif
+#ifndef PT_WF_RPW_LDS
+#define PT_WF_RPW_LDS 128
+#endif
+constexpr int kWfRaysPerWave = PT_WF_RPW;
+constexpr int kWfRaysPerWaveLds = PT_WF_RPW_LDS;      // the 768-thread instance (whole tree in LDS)
 constexpr int kWfSuspendLanes = 48;     // 8 / 16 / 32 / 48 -> 749 / 752 / 763 / 773 Msamples/s (flat loop 700)
 
 // Traversal with lane refill: a trip = while-while rounds until most lanes are done; a lane whose ray is
@@ -249,25 +275,19 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
     // a block whose rays were cheap takes over from one whose rays were not (static striding left 1.7 trips per block with
     // nothing to balance them: profiles/r03/b_*)
     __shared__ unsigned s_next_base;
+    // ... and INSIDE a trip the block's waves share its RPB rays dynamically: a wave takes the next 64 of them from a cursor in
+    // LDS whenever its own range has run dry, so the waves of a block finish a trip together whatever their rays cost (with a
+    // fixed 128 rays per wave the trip ended on its slowest wave, eleven others waiting at the barrier below)
+    __shared__ unsigned s_cursor;
+    if (threadIdx.x == 0) s_cursor = 0;
+    __syncthreads();
     unsigned block_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * RPB));
     const unsigned first_dynamic = gridDim.x * RPB;
     for (;;) {
-        unsigned cbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(block_base + wave * RPW));  // uniform per wave: next unassigned ray
-        const unsigned cend = (unsigned)__builtin_amdgcn_readfirstlane((int)min(cbase + (unsigned)RPW, n));
-        if (cbase > cend) cbase = cend;
+        const unsigned nblock = (unsigned)__builtin_amdgcn_readfirstlane((int)min((unsigned)RPB, n - block_base));
+        unsigned cbase = 0, cend = 0;        // uniform per wave: the unassigned rest of the range the wave holds
+        bool exhausted = false;              // the block's trip has no ray left to hand out
         Trav<MODE> tr;
-        // the big-triangle list first, for the wave's whole range with every lane busy: the hit record of a ray
-        // starts out as its closest hit among them (the flat loop below would run this per refilled lane)
-        if (sv.n_flat > 0) {
-            for (unsigned r = cbase + (threadIdx.x & 63); r < cend; r += 64) {
-                const float4 A = rsA[r];
-                const float2 Bq = *reinterpret_cast<const float2*>(&rsB[r]);
-                tr.begin(mk(A.x, A.y, A.z), mk(A.w, Bq.x, Bq.y), stk);
-                tr.template flat_pass<false>(sv, &wc);
-                hits[r] = make_float2(tr.best_t, __int_as_float(tr.best));
-            }
-            __threadfence_block();       // the records are read back by other lanes of this wave
-        }
         tr.begin(mk(0.f, 0.f, 0.f), mk(0.f, 0.f, 1.f), stk);
         tr.idle();
         unsigned pos = ~0u;          // stream position of the ray in flight (~0u: none)
@@ -276,6 +296,44 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
         float2 nB = make_float2(0.f, 1.f);
         float2 nH = make_float2(0.f, 0.f);
         for (;;) {
+            // ---- the wave's range has run dry: take the next 64 rays of the block's trip
+            if (cbase >= cend && !exhausted) {
+                unsigned off = 0;
+                if ((threadIdx.x & 63) == 0) off = atomicAdd(&s_cursor, 64u);
+                off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+                if (off < nblock) {
+                    cbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(block_base + off));
+                    cend = (unsigned)__builtin_amdgcn_readfirstlane((int)(block_base + min(off + 64u, nblock)));
+                    // the big-triangle list first, for all 64 with every lane busy: the hit record of a ray starts out as its
+                    // closest hit among them (per refilled lane it would run for the few lanes that switch rays together).  The
+                    // lanes are in mid-traversal: what a resumed traversal cannot recompute from its ray is set aside
+                    if (sv.n_flat > 0) {
+                        const f3 sP_ = tr.P, sD_ = tr.D;
+                        const float s_bt = tr.best_t;
+                        const int s_b = tr.best, s_cur = tr.cur, s_pend = tr.pend;
+                        char* const s_tos = tr.tos;
+                        const unsigned r = cbase + (threadIdx.x & 63);
+                        if (r < cend) {
+                            const float4 A = rsA[r];
+                            const float2 Bq = *reinterpret_cast<const float2*>(&rsB[r]);
+                            tr.setup(mk(A.x, A.y, A.z), mk(A.w, Bq.x, Bq.y));
+                            tr.best_t = __builtin_inff();
+                            tr.best = -1;
+                            tr.template flat_pass<false>(sv, &wc);
+                            hits[r] = make_float2(tr.best_t, __int_as_float(tr.best));
+                        }
+                        __threadfence_block();       // the records are read back by other lanes of this wave
+                        tr.setup(sP_, sD_);
+                        tr.best_t = s_bt;
+                        tr.best = s_b;
+                        tr.cur = s_cur;
+                        tr.pend = s_pend;
+                        tr.tos = s_tos;
+                    }
+                } else {
+                    exhausted = true;
+                }
+            }
             // ---- lanes whose ray is finished switch to their prefetched ray
             if (tr.done() && npos != ~0u) {
                 pos = npos;
@@ -298,7 +356,10 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
                 }
                 cbase = (unsigned)__builtin_amdgcn_readfirstlane((int)min(cbase + (unsigned)__popcll(want), cend));
             }
-            if (__ballot(!tr.done() || npos != ~0u) == 0) break;
+            if (__ballot(!tr.done() || npos != ~0u) == 0) {
+                if (exhausted) break;
+                continue;                    // nothing in flight, but the block may still have rays: take the next 64
+            }
             // ---- while-while rounds until at most kWfSuspendLanes lanes are unfinished (and one has finished): the
             // megakernel's tail suspension, with the refill from the ray stream above in the place of shading.
             // (A flat loop -- one node visit and one triangle test per lane and iteration -- ran both bodies every
@@ -323,7 +384,6 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
         }
         // ---- order-preserving compaction of the trip's rays into the three class queues
         __syncthreads();
-        const unsigned nblock = min((unsigned)RPB, n - block_base);
         unsigned off[RPB / BLOCK];
         int cl[RPB / BLOCK];
 #pragma unroll
@@ -355,7 +415,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
             unsigned t = 0;
             if ((threadIdx.x & 63) == 0) t = atomicAdd(&ctr[5 + cost], (unsigned)RPB);
             t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-            if ((threadIdx.x & 63) == 0) s_next_base = first_dynamic + t;
+            if ((threadIdx.x & 63) == 0) { s_next_base = first_dynamic + t; s_cursor = 0; }
         }
         __syncthreads();            // (also: lds_cls / lds_cnt are rewritten by the next trip)
         block_base = (unsigned)__builtin_amdgcn_readfirstlane((int)s_next_base);
@@ -376,41 +436,47 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
     int li[kWfShadePerThread];
     int cost[kWfShadePerThread];                          // >= 0: the path continues with a ray of that cost class
     unsigned flags[kWfShadePerThread];
-    f3 rP[kWfShadePerThread], rD[kWfShadePerThread];
+    int seeds[kWfShadePerThread];
+    f3 rP[kWfShadePerThread], rD[kWfShadePerThread], fLs[kWfShadePerThread];
 #pragma unroll
     for (int k = 0; k < kWfShadePerThread; ++k) {
         const unsigned i = (blockIdx.x * kWfShadePerThread + k) * kWfShadeBlock + threadIdx.x;
         li[k] = 0;
         cost[k] = -1;
         flags[k] = 0;
+        seeds[k] = 0;
+        fLs[k] = mk(1.f, 1.f, 1.f);
         rP[k] = mk(0.f, 0.f, 0.f);
         rD[k] = mk(0.f, 0.f, 1.f);
         if (i < n) {
             const unsigned e = (unsigned)w.q_cls[cls][i];
             const int c_in = (int)(e >> 31);
             const unsigned pos = e & 0x7fffffffu;
-            const float4 A = w.rsA[bounce & 1][c_in][pos], B = w.rsB[bounce & 1][c_in][pos];
+            const float4 A = w.rsA[bounce & 1][c_in][pos], B = w.rsB[bounce & 1][c_in][pos], Cq = w.rsC[bounce & 1][c_in][pos];
             li[k] = __float_as_int(B.z);
             PathInHbm st;
             st.base = w.sP + (size_t)li[k] * 3;
-            st.fstride = (size_t)w.npix * 3;
+            st.fstride = (size_t)w.npix_all * 3;
             st.flags = (unsigned)__float_as_int(B.w);
+            st.fL = mk(Cq.x, Cq.y, Cq.z);
+            int seed = __float_as_int(Cq.w);
             if (cls == 2) {                                   // miss: black environment, prog.cl:367-376
                 wf_finalize(w, li[k], st.C());
+                p.rnds[li[k]] = seed;
             } else {
                 const float2 h = w.hit[c_in][pos];
                 rP[k] = mk(A.x, A.y, A.z);
                 rD[k] = mk(A.w, B.x, B.y);
-                int seed = p.rnds[li[k]];
-                const int seed_in = seed;
                 bool inside = (st.flags & (unsigned)kWfInsideBit) != 0;
                 shade_hit<false>(rP[k], rD[k], st, seed, inside, p, p.tris, p.meta, __float_as_int(h.y), h.x);
-                if (seed != seed_in) p.rnds[li[k]] = seed;
                 if (bounce + 1 >= p.iterations) {
                     wf_finalize(w, li[k], st.C());
+                    p.rnds[li[k]] = seed;
                 } else {
                     flags[k] = (st.flags & ~(unsigned)kWfInsideBit) | (inside ? (unsigned)kWfInsideBit : 0u);
                     cost[k] = ray_cost_class(w, rP[k], rD[k]);
+                    fLs[k] = st.fL;
+                    seeds[k] = seed;
                 }
             }
         }
@@ -422,6 +488,7 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
         if (cost[k] >= 0) {
             w.rsA[(bounce + 1) & 1][cost[k]][npos[k]] = make_float4(rP[k].x, rP[k].y, rP[k].z, rD[k].x);
             w.rsB[(bounce + 1) & 1][cost[k]][npos[k]] = make_float4(rD[k].y, rD[k].z, __int_as_float(li[k]), __int_as_float((int)flags[k]));
+            w.rsC[(bounce + 1) & 1][cost[k]][npos[k]] = make_float4(fLs[k].x, fLs[k].y, fLs[k].z, __int_as_float(seeds[k]));
         }
 }
 
@@ -458,8 +525,8 @@ hipError_t launch_wf_intersect(const WfParams& w, int bounce, int cu_count, hipS
     // fits, else two of 512; nodes from global memory -> six / seven 256-thread workgroups per CU
     switch (w.rp.node_mode) {
     case kNodesLds:
-        if (2 * (wf_intersect_lds<kNodesLds, kLdsBlockWide, kLdsWpsWide, 128>(w) + 512) <= 160 * 1024)
-            return launch_wf_intersect_t<kNodesLds, kLdsBlockWide, kLdsWpsWide, 128>(w, bounce, cu_count * 2, stream);
+        if (2 * (wf_intersect_lds<kNodesLds, kLdsBlockWide, kLdsWpsWide, kWfRaysPerWaveLds>(w) + 512) <= 160 * 1024)
+            return launch_wf_intersect_t<kNodesLds, kLdsBlockWide, kLdsWpsWide, kWfRaysPerWaveLds>(w, bounce, cu_count * 2, stream);
         return launch_wf_intersect_t<kNodesLds, 512, 4, kWfRaysPerWave>(w, bounce, cu_count * 2, stream);
     case kNodesGlobal: return launch_wf_intersect_t<kNodesGlobal, 256, 6, kWfRaysPerWave>(w, bounce, cu_count * 6, stream);
     case kNodesWide: return launch_wf_intersect_t<kNodesWide, 256, 6, kWfRaysPerWave>(w, bounce, cu_count * 6, stream);
