@@ -101,6 +101,10 @@ struct pt_context {
     uint32_t* d_wf_counters = nullptr;   // kWfMaxChains x (kWfMaxBounces + 4) rows
     hipStream_t wf_stream[kWfMaxChains] = {};   // chains 1.. of the wavefront variant (chain 0 runs on `stream`)
     hipEvent_t wf_event[kWfMaxChains] = {};
+    int poll_timeout_ms = 2000;          // chained passes: a wave gives a tile's previous pass this long before it reports the hand-over lost
+    int debug_stall_tile = -1;           // tests: pass 0 of this tile is never published
+    bool counters_suspect = false;
+    bool launched_since_check = false;   // a persistent launch has been enqueued since the work counter's error word was last read       // a launch failed or lost a hand-over: word 0 / 1 of d_tile_counter may not be back at zero
     int wf_streams = -1;                 // option wf_streams: chains of the wavefront variant (-1: kWfDefaultChains)
     bool own_rnds = true, own_colors = true;
     hipStream_t stream = nullptr;
@@ -935,6 +939,12 @@ std::vector<int32_t> select_flat_list(const pt_context* ctx, std::vector<BuildPr
     return flat;
 }
 
+// Which SAH tree a bvh_policy stands for, read by the host builder (build_and_pack) AND the device builder (build_on_device) so that
+// a build that falls back from the device to the host -- a host-only context, non-finite triangles, a median split, eight
+// triangles or fewer -- gives the tree the option names: 5 ("the SAH tree, built on the device") is policy 0's tree; 4 (device
+// LBVH) has no host form and falls back to policy 0's tree as well.
+int tree_policy(const pt_context* ctx) { return ctx->bvh_policy >= 4 ? 0 : ctx->bvh_policy; }
+
 int build_and_pack(pt_context* ctx) {
     PhaseClock clk("pt_upload_triangles");
     const size_t n = ctx->tris.size();
@@ -971,8 +981,9 @@ int build_and_pack(pt_context* ctx) {
     std::vector<int32_t> flat = select_flat_list(ctx, prims);
     clk.lap("big-triangle list");
     BvhBuilder bld;
-    int rc = ctx->bvh_policy <= 1 ? build_attempt(ctx, bld, prims, flat, 4, false)
-                                  : build_attempt(ctx, bld, prims, flat, ctx->bvh_policy == 2 ? 4 : 8, true);
+    // (the SAH tree of a policy is the same on the host and on the device: tree_policy() is read by both builders)
+    const int tp = tree_policy(ctx);
+    int rc = tp <= 1 ? build_attempt(ctx, bld, prims, flat, 4, false) : build_attempt(ctx, bld, prims, flat, tp == 2 ? 4 : 8, true);
     if (rc != PT_OK) return rc;
     clk.lap("SAH build");
     ctx->n_flat = (int)flat.size();
@@ -1296,13 +1307,17 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
         p->stack_ovf_lanes = (int32_t)ctx->stack_ovf_lanes;
     }
     p->tile_counter = nullptr;
+    p->poll_ticks = (uint32_t)std::min<int64_t>((int64_t)ctx->poll_timeout_ms * 100000, 0xffffffffll);      // s_memrealtime: 100 MHz
+    p->debug_stall_tile = ctx->debug_stall_tile;
     p->chunk_spp = 0;
     p->tile_done = nullptr;
     p->n_tiles = ((ctx->W + 7) / 8) * ((ctx->local_rows + 7) / 8);
     // measured with the big-triangle list in place (profiles/r02/i_*): Cornell box in LDS 8 / 16 / 24 / 32 -> 1669 / 1690 /
     // 1680 / 1669 Msamples/s (lockstep 1671); MESH-100k 24 / 32 / 48 -> 600 / 599 / 595 (lockstep 571); MESH-1M 211 / 210 / 205 (191)
     // (re-swept at the end of the round: Cornell box 8 / 12 / 16 / 20 / 24 / 32 -> 1957 / 2033 / 2066 / 2074 / 2078 / 2070)
-    p->suspend_lanes = ctx->suspend_lanes >= 0 ? ctx->suspend_lanes : 24;
+    // (round 4, with the phase switching below: tree in LDS 12 / 16 / 20 / 24 / 32 -> 2637 / 2638 / 2621 / 2607 / 2554; from global
+    // memory the rate is flat from 16 to 24: profiles/r04/)
+    p->suspend_lanes = ctx->suspend_lanes >= 0 ? ctx->suspend_lanes : (p->node_mode == kNodesLds ? 16 : 24);
     // a phase of a while-while round ends early when at most this many lanes are still in it and some lane has left it
     // (Trav::round).  1080p, node_min / leaf_min (profiles/r04/c_*): tree in LDS (Cornell box) 0/0 2436, 3/4 2589, 4/8 2590, 8/4 2506
     // Msamples/s; 4-wide nodes from global memory 0/0 839 | 294, 4/4 1012 | 367, 6/4 1028 | 373, 8/8 1031 | 371 (MESH-100k | MESH-1M)
@@ -1783,8 +1798,9 @@ static int build_on_device(pt_context* ctx, bool* done) {
     const bool sah = ctx->bvh_policy != 4;
     if (sah) {                                  // the host builder's tree, node for node; the host builds what the device cannot
         bool unsupported = false;
-        const bool forced = ctx->bvh_policy == 2 || ctx->bvh_policy == 3;            // (as build_and_pack reads the policy)
-        PT_HIP(ctx, sah_device_build(st.d_tris, st.d_rank, n, d_sel, ns, ctx->bvh_policy == 3 ? 8 : 4, forced, (float)ctx->sah_visit_cost * 0.1f, ctx->sah_grain, ctx->stream, &r,
+        const int tp = tree_policy(ctx);
+        const bool forced = tp == 2 || tp == 3;            // (as build_and_pack reads the policy)
+        PT_HIP(ctx, sah_device_build(st.d_tris, st.d_rank, n, d_sel, ns, tp == 3 ? 8 : 4, forced, (float)ctx->sah_visit_cost * 0.1f, ctx->sah_grain, ctx->stream, &r,
                                      &unsupported));
         if (unsupported) return PT_OK;
         clk.lap("sah_device_build");
@@ -1955,6 +1971,18 @@ int pt_upload_seeds(pt_context* ctx, const int32_t* seeds, int64_t n) {
     return seed_upload(ctx, seeds);
 }
 
+// The work counter of the persistent launches (d_tile_counter) is zeroed once, at pt_create: every launch that runs to its end leaves
+// words 0 / 1 at zero (the last wave out resets them).  INVARIANT: a launch that did NOT run to its end -- a failed launch call, a
+// failed synchronize, a lost hand-over -- sets counters_suspect, and the next launch clears the counter first.
+static int prepare_work_counter(pt_context* ctx) {
+    if (ctx->counters_suspect) {
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counter, 0, 64, ctx->stream));
+        ctx->counters_suspect = false;
+    }
+    ctx->launched_since_check = true;
+    return PT_OK;
+}
+
 static int ptamd_resident_waves(const pt_context*, const LaunchConfig& lc) { return lc.persistent_blocks * (lc.block / 64); }
 
 // Samples per (pass, tile) work item of a persistent launch, by tiles per resident wave (0: whole tiles).
@@ -1990,6 +2018,7 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
             if ((size_t)w * lc->lds_bytes + 1024 <= kLdsPerCu) { lc->waves_per_simd = w; break; }
     }
     lc->persistent_blocks = ctx->cu_count * std::max(1, 256 * lc->waves_per_simd / lc->block);
+    lc->cu_count = ctx->cu_count;
     // ... and with few samples per launch: a lane has no next sample to start while the others finish, and lanes that run
     // ahead give up the coherence of a tile's camera rays -- lockstep up to 4 samples per launch with the tree in LDS
     // (render(1): 1,810 against 1,492 Msamples/s), for one sample otherwise (profiles/r03/q_*)
@@ -2024,13 +2053,19 @@ int pt_trace_rays(pt_context* ctx, const pt_camera* cam, int32_t iterations, int
     LaunchConfig lc;
     launch_cfg(ctx, p, &lc);
     if (ctx->persistent) {      // the grid only fills the chip: a workgroup stages the tree once, not once per eight tiles
+        if (int rc2 = prepare_work_counter(ctx)) return rc2;
         p.tile_counter = ctx->d_tile_counter;      // (zero: the previous launch's last wave reset it)
     }
     EventPair* ep;
     if ((rc = time_begin(ctx, &ep)) != PT_OK) return rc;
-    PT_HIP(ctx, launch_trace_ray(p, lc, ctx->stream));
+    {
+        const hipError_t le = launch_trace_ray(p, lc, ctx->stream);
+        if (le != hipSuccess) { ctx->counters_suspect = true; return fail(ctx, PT_EHIP, std::string("launch_trace_ray: ") + hipGetErrorString(le)); }
+    }
     ctx->render_epoch++;
-    return time_end(ctx, ep);
+    rc = time_end(ctx, ep);
+    if (rc != PT_OK) ctx->counters_suspect = true;
+    return rc;
 }
 
 // The stream-compacted variant.  The local pixels are cut into `wf_streams` contiguous chains; every chain owns its ray streams,
@@ -2142,6 +2177,7 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
     LaunchConfig lc;
     launch_cfg(ctx, p, &lc);
     if (ctx->persistent) {
+        if (int rc2 = prepare_work_counter(ctx)) return rc2;
         p.tile_counter = ctx->d_tile_counter;      // (zero: the previous launch's last wave reset it)
         // automatic: chaining passes only pays when there are enough tiles to re-balance; with about one
         // tile per resident wave (a 1080p frame over 8 GPUs) the most expensive tile is the critical path
@@ -2171,8 +2207,11 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
     }
     EventPair* ep;
     if ((rc = time_begin(ctx, &ep)) != PT_OK) return rc;
-    PT_HIP(ctx, launch_render_mega(p, lc, ctx->stream));
-    if ((rc = time_end(ctx, ep)) != PT_OK) return rc;
+    {
+        const hipError_t le = launch_render_mega(p, lc, ctx->stream);
+        if (le != hipSuccess) { ctx->counters_suspect = true; return fail(ctx, PT_EHIP, std::string("launch_render_mega: ") + hipGetErrorString(le)); }
+    }
+    if ((rc = time_end(ctx, ep)) != PT_OK) { ctx->counters_suspect = true; return rc; }
     ctx->current_sample += nsamples;  // main.cpp:686
     return PT_OK;
 }
@@ -2188,11 +2227,36 @@ int pt_get_current_sample(const pt_context* ctx, int32_t* out) {
     return PT_OK;
 }
 
+// Wait for the context's stream, then look at what the kernels left behind: a launch that lost a hand-over between chained passes
+// (k_render) has written the tile into the work counter's error word.  That, like any failed HIP call on the way, becomes PT_EHIP --
+// and the work counter is cleared before the next launch (a launch that did not run to its end does not leave words 0 / 1 at zero).
+static int sync_and_check(pt_context* ctx) {
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ctx->counters_suspect = true;
+        return fail(ctx, PT_EHIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
+    if (!ctx->launched_since_check || !ctx->d_tile_counter) return PT_OK;
+    ctx->launched_since_check = false;
+    uint32_t words[8] = {};
+    PT_HIP(ctx, hipMemcpy(words, ctx->d_tile_counter, sizeof words, hipMemcpyDeviceToHost));
+    if (words[kTileCounterError] != 0) {
+        ctx->counters_suspect = true;
+        PT_HIP(ctx, hipMemset(ctx->d_tile_counter, 0, 64));
+        ctx->counters_suspect = false;
+        char msg[256];
+        std::snprintf(msg, sizeof msg, "k_render: pass %u of tile %u waited more than %d ms for the tile's previous pass to be handed over (the "
+                      "wave rendering it was lost); the launch was wound down, the frame is incomplete", words[kTileCounterError + 1],
+                      words[kTileCounterError] - 1, ctx->poll_timeout_ms);
+        return fail(ctx, PT_EHIP, msg);
+    }
+    return PT_OK;
+}
+
 int pt_sync(pt_context* ctx) {
     PT_NEED_DEVICE(ctx);
-    PT_HIP(ctx, hipSetDevice(ctx->device));
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PT_OK;
+    return sync_and_check(ctx);
 }
 
 int pt_local_pixel_count(const pt_context* ctx, int64_t* out) {
@@ -2293,8 +2357,8 @@ int pt_local_pixel_ids(const pt_context* ctx, int32_t* out, int64_t n) {
 }
 
 static int read_back(pt_context* ctx, void* dst, const void* src, size_t bytes) {
-    PT_HIP(ctx, hipSetDevice(ctx->device));
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int rc = sync_and_check(ctx);
+    if (rc != PT_OK) return rc;
     if (bytes) PT_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return PT_OK;
 }
@@ -2408,6 +2472,12 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 32) return fail(ctx, PT_EINVAL, "flat_list: 0..32 big triangles tested before the tree (a 32-bit candidate mask per lane)");
         ctx->flat_list = (int)value;
         ctx->tris_uploaded = false;
+    } else if (k == "poll_timeout_ms") {
+        if (value < 1 || value > 40000) return fail(ctx, PT_EINVAL, "poll_timeout_ms: 1..40000");
+        ctx->poll_timeout_ms = (int)value;
+    } else if (k == "debug_stall_tile") {
+        if (value < -1 || value > 0x7fffffff) return fail(ctx, PT_EINVAL, "debug_stall_tile: -1 none, or a tile index");
+        ctx->debug_stall_tile = (int)value;
     } else if (k == "wf_streams") {
         if (value < -1 || value == 0 || value > kWfMaxChains) return fail(ctx, PT_EINVAL, "wf_streams: -1 default, 1..8");
         ctx->wf_streams = (int)value;

@@ -70,6 +70,7 @@ constexpr int64_t kMaxTriangles = (int64_t)1 << 26;
 constexpr int64_t kDeviceBuildFrom = 16384;   // SAH trees of scenes this big are built on the device by default (same tree; mesh6k: 2.4 vs 2.8 ms, 1M: 15 vs 99)
 constexpr int kMaxLeaf = 4;        // triangles per leaf (<= 8 by the reference encoding)
 constexpr int kMaxDepth = 30;      // builder guarantees depth <= kMaxDepth
+constexpr int kTileCounterError = 4;   // word of RenderParams::tile_counter that holds 1 + tile of a lost hand-over (word 5: the pass)
 constexpr int kStatRows = 256;     // statistics counters are spread over this many rows of kStatCols
 constexpr int kStatCols = 16;
 // k_render instances whose register budget is set for this many waves per SIMD or more carry nothing across a traversal
@@ -123,7 +124,11 @@ struct RenderParams {
                                  // above the top); kNodesWide: at most kWideLdsEntries, the rest of the worst case in stack_ovf
     uint32_t* stack_ovf;         // kNodesWide: [entries past the LDS part][lane of the grid], or null when LDS holds the worst case
     int32_t stack_ovf_lanes;     // lanes stack_ovf has room for (every launch's grid must fit)
-    uint32_t* tile_counter;      // != 0: persistent launch, waves pull tile indices from word 0; word 1 counts the waves that left (the last resets both)
+    uint32_t* tile_counter;      // != 0: persistent launch, waves pull tile indices from word 0; word 1 counts the waves that left (the last resets
+                                 // both); words 4 / 5: 1 + tile and pass of a hand-over that never came (kTileCounterError), left for the host
+    uint32_t poll_ticks;         // chained passes: how long a wave waits for a tile's previous pass, in 10-ns ticks of s_memrealtime, before it
+                                 // reports the tile in word 4 and the launch winds down (pt_sync then returns PT_EHIP)
+    int32_t debug_stall_tile;    // tests: pass 0 of this tile is rendered but never published (-1: none)
     int32_t n_tiles;
     int32_t chunk_spp;           // > 0: a work item is (pass, tile) = chunk_spp samples of a tile; passes of one
                                  // tile are chained through tile_done[] (agent-scope release / acquire)
@@ -213,7 +218,8 @@ hipError_t wide_device_build(const float4* d_bvh2, int n_nodes, hipStream_t stre
 struct LaunchConfig {
     int block = 256;                   // traversal_block(node_mode)
     size_t lds_bytes = 0;              // traversal_lds_bytes()
-    int persistent_blocks = 1 << 30;   // grid size of a persistent launch (workgroups that fit the chip)
+    int persistent_blocks = 1 << 30;   // grid size of a persistent launch (workgroups that fit the chip): what launch_cfg expects to be resident
+    int cu_count = 0;                  // compute units of the device (> 0: the grid is also capped by what the runtime says can co-reside)
     bool count_work = false;           // also count node visits / triangle tests into stats[2..9]
     int schedule = 0;                  // megakernel: 0 lockstep per sample, 1 restart + tail suspension (pt_kernels.hip)
     int waves_per_simd = 4;            // register budget of the k_render instance: 4, or 5 / 6 / 7 for nodes from global memory
@@ -238,6 +244,25 @@ inline hipError_t ensure_dynamic_lds(const void* kern, LdsMark& mark, size_t lds
     size_t seen = mark.bytes[dev].load(std::memory_order_relaxed);
     while (seen < lds_bytes && !mark.bytes[dev].compare_exchange_weak(seen, lds_bytes, std::memory_order_release)) {}
     return hipSuccess;
+}
+
+// Workgroups of `kern` (BLOCK threads, lds_bytes of dynamic LDS) that can be resident on one CU according to the runtime, asked
+// once per kernel instance, device and LDS size.  A persistent grid is capped by it: launch_cfg's own figure is derived from the
+// register budget the instance was compiled for, and a grid LARGER than what is co-resident would leave workgroups queued behind
+// waves that poll for a hand-over (harmless for correctness -- a producer is always dequeued before its consumer -- but it is not
+// the launch shape the schedules were tuned for).  0: the runtime gave no answer.
+struct OccMark {
+    std::atomic<long long> key[kMaxDevicesPerProcess];      // (lds_bytes << 8) | blocks per CU
+};
+inline int resident_blocks_per_cu(const void* kern, OccMark& mark, int block, size_t lds_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesPerProcess) return 0;
+    const long long seen = mark.key[dev].load(std::memory_order_acquire);
+    if (seen != 0 && (size_t)(seen >> 8) == lds_bytes) return (int)(seen & 0xff);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, block, lds_bytes) != hipSuccess || n <= 0) return 0;
+    mark.key[dev].store(((long long)lds_bytes << 8) | (long long)std::min(n, 255), std::memory_order_release);
+    return n;
 }
 
 // PTAMD_TRACE=1: phase times of the host-side scene path on stderr (pt_add_obj, pt_upload_triangles; tools/obj_load_time.py)

@@ -276,13 +276,32 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
             tile = t - pass * p.n_tiles;
             if (chained ? pass >= n_pass : tile >= p.n_tiles) break;
             if (pass > 0) {                                      // ---- acquire the tile's previous pass
-                unsigned seen = 0;
+                // The producer was dequeued earlier by a resident wave, so the wait ends -- unless that wave died (a fault in its
+                // item) or the launch is already winding down.  The poll is therefore BOUNDED: after poll_ticks (2 s by default) the
+                // wave reports the tile in tile_counter[kTileCounterError] and leaves; every other waiting wave sees that word and
+                // leaves too, the launch drains, and the host turns the word into PT_EHIP (pt_sync) instead of a hung process.
+                unsigned seen = 0, lost = 0;
+                const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
                 for (;;) {
-                    if (lane0) seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane0) {
+                        seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lost = __hip_atomic_load(&p.tile_counter[kTileCounterError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
-                    if (seen >= (unsigned)pass) break;
+                    lost = (unsigned)__builtin_amdgcn_readfirstlane((int)lost);
+                    if (seen >= (unsigned)pass || lost != 0) break;
+                    if (__builtin_amdgcn_s_memrealtime() - w0 > (unsigned long long)p.poll_ticks) {
+                        // (tile and pass in ONE 8-byte compare-and-swap: the first wave to give up names them)
+                        const unsigned long long mine = ((unsigned long long)(unsigned)pass << 32) | (unsigned long long)((unsigned)tile + 1u);
+                        unsigned long long was = 0;
+                        if (lane0) was = atomicCAS(reinterpret_cast<unsigned long long*>(&p.tile_counter[kTileCounterError]), 0ull, mine);
+                        const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)was);
+                        lost = first != 0 ? first : (unsigned)tile + 1u;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(8);
                 }
+                if (seen < (unsigned)pass) break;                // a hand-over was lost somewhere: this wave renders nothing more
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         }
@@ -313,7 +332,8 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
         if (chained) {                                           // ---- release this pass of the tile
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // keep the wait the compiler may drop (guide, G16)
-            if (lane0) __hip_atomic_store(&p.tile_done[tile], (unsigned)(pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane0 && !(tile == p.debug_stall_tile && pass == 0))
+                __hip_atomic_store(&p.tile_done[tile], (unsigned)(pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (!p.tile_counter) break;
     }
@@ -442,6 +462,11 @@ static hipError_t launch_one(const RenderParams& p, const LaunchConfig& lc, hipS
     static LdsMark mark;
     const hipError_t e = ensure_dynamic_lds((const void*)kern, mark, lc.lds_bytes);
     if (e != hipSuccess) return e;
+    if (p.tile_counter && lc.cu_count > 0) {         // a persistent grid: never more workgroups than the runtime says are co-resident
+        static OccMark occ;
+        const int per_cu = resident_blocks_per_cu((const void*)kern, occ, BLOCK, lc.lds_bytes);
+        if (per_cu > 0) blocks = std::min(blocks, per_cu * lc.cu_count);
+    }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), lc.lds_bytes, stream, p);
     return hipGetLastError();
 }

@@ -384,11 +384,13 @@ hipError_t wide_device_build(const float4* d_bvh2, int n_nodes, hipStream_t stre
     const int head = std::min(misc[1], total);
     *max_pending = misc[2];
     // 3b. the blocks: subtrees head .. T-1 in that order behind the breadth-first part
+    std::vector<int> d, F;           // function scope: F is the source of an asynchronous copy and must outlive it
     if (head < total) {
         int T = 0;
         WD_HIP(hipMemcpy(&T, w.first + head, sizeof(int), hipMemcpyDeviceToHost));
         const int nt = T - head;
-        std::vector<int> d((size_t)nt), F((size_t)nt);
+        d.resize((size_t)nt);
+        F.resize((size_t)nt);
         WD_HIP(hipMemcpy(d.data(), w.desc + head, sizeof(int) * (size_t)nt, hipMemcpyDeviceToHost));
         int at = T;
         for (int t = 0; t < nt; ++t) { F[(size_t)t] = at; at += d[(size_t)t]; }

@@ -1225,3 +1225,40 @@ def test_work_item_counter_range_is_checked(api, cb_spec):
     assert sc.current_sample == 0
     sc.render(2)                            # the context is still usable
     assert sc.current_sample == 2
+
+
+def test_lost_hand_over_becomes_an_error_not_a_hang(api, cb_spec):
+    """Chained passes hand a tile's rnds / colors from wave to wave through tile_done[] (k_render).  If the wave that owes a tile's
+    pass never publishes it -- injected here with the debug option `debug_stall_tile`: pass 0 of tile 37 is rendered but not
+    released -- the consumers' poll is BOUNDED: the launch winds down and pt_sync returns PT_EHIP naming the tile and the pass,
+    instead of spinning until the driver's timeout.  The context recovers: work counter cleared, the next launch is right."""
+    import time
+    W = H = 256
+    ref = api.Scene(W, H).load(cb_spec)
+    ref.iterations = 4
+    ref.set_option("chunk_spp", 2)
+    ref.render(8)
+    want_c, want_r = ref.read_colors(), ref.read_rnds()
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.iterations = 4
+    sc.set_option("chunk_spp", 2)
+    sc.set_option("poll_timeout_ms", 60)
+    sc.set_option("debug_stall_tile", 37)
+    t0 = time.time()
+    sc.render(8)
+    with pytest.raises(api.PtError) as e:
+        sc.sync()
+    assert e.value.code == api.PT_EHIP and "pass 1 of tile 37" in str(e.value), str(e.value)
+    assert time.time() - t0 < 20.0
+    # every other tile was rendered to the end (the launch drained, it was not killed)
+    got = sc.read_colors().reshape(H, W, 4)
+    bad = np.zeros((H, W), dtype=bool)
+    bad[(37 // (W // 8)) * 8:(37 // (W // 8)) * 8 + 8, (37 % (W // 8)) * 8:(37 % (W // 8)) * 8 + 8] = True
+    assert same_bits(got[~bad], want_c.reshape(H, W, 4)[~bad])
+    # ... and the context is usable again
+    sc.set_option("debug_stall_tile", -1)
+    sc.current_sample = 0
+    sc.seed_default()
+    sc.render(8)
+    assert same_bits(sc.read_colors(), want_c) and np.array_equal(sc.read_rnds(), want_r)
+    assert sc.stat("samples") >= W * H * 8

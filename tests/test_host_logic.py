@@ -305,3 +305,32 @@ def test_launch_plan_of_a_rank_of_eight(api, cb_spec):
     assert (p4["block"], p4["schedule"], p4["chunk_spp"]) == (768, 0, 8), p4
     k8 = plan(3840, 2160, 5, 8)             # 16,320 tiles: 2.7 per resident wave
     assert (k8["block"], k8["waves_per_simd"], k8["schedule"], k8["chunk_spp"]) == (768, 6, 0, 8), k8
+
+
+def test_device_policies_fall_back_to_the_tree_they_name(api):
+    """bvh_policy 5 is "policy 0's SAH tree, built on the device", and a build that cannot run there -- a host-only context,
+    a scene with a non-finite triangle -- must come back with THAT tree from the host builder, node for node (round 3 fell back
+    to policy 3's tree, leaves of <= 8 forced).  Policy 4 (device LBVH) has no host form: it falls back to policy 0's tree too."""
+    from opencl_path_tracer_amd import scenes
+    spec = scenes.displaced_grid_mesh(6000)
+    nan_spec = scenes.displaced_grid_mesh(6000)
+    v, m = nan_spec.objects[1]
+    v = v.copy()
+    v[1234, 1, 2] = np.nan
+    nan_spec.objects[1] = (v, m)
+    for s in (spec, nan_spec):
+        ref = None
+        for policy in (0, 5, 4):
+            sc = api.Scene(64, 64, device=None)
+            sc.set_option("bvh_policy", policy)
+            sc.load(s)
+            nodes, tris, meta, orig = sc.debug_bvh()
+            got = (nodes.tobytes(), orig.tobytes(), int(sc.stat("bvh_depth")))
+            if ref is None:
+                ref = got
+            assert got == ref, "policy %d on a host-only context is not policy 0's tree" % policy
+    # ... and the forced-leaf policies still differ from it (the comparison above is not vacuous)
+    sc = api.Scene(64, 64, device=None)
+    sc.set_option("bvh_policy", 3)
+    sc.load(spec)
+    assert sc.debug_bvh()[0].tobytes() != ref[0]

@@ -1,5 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; out=gpurun_out/r4q; mkdir -p $out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "wavefront or variant or closed or replay" > $out/tests_wf.log 2>&1; rc=$?; tail -3 $out/tests_wf.log; [ $rc -ne 0 ] && exit 1
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; rc=$?; tail -5 $out/tests.log; [ $rc -ne 0 ] && exit 1
 python - > $out/wf_streams.txt 2>&1 <<'PY'
 import sys, time
 sys.path.insert(0, ".")
@@ -18,3 +18,4 @@ for name, make, b, spp in (("cornell", scenes.cornell_box, 8, 8), ("mesh100k", l
     sc.close()
 PY
 cat $out/wf_streams.txt
+timeout -k 10 400 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; tail -3 $out/bench.err; cut -c1-600 $out/bench.json
