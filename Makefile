@@ -10,8 +10,8 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-s
 
 all: $(PKG)/libptamd.so oracle tests/cpp/dropin check-isa
 
-SRCS    := $(CSRC)/pt_host.cpp $(CSRC)/pt_obj.cpp $(CSRC)/pt_kernels.hip $(CSRC)/pt_wavefront.hip $(CSRC)/pt_debug.hip $(CSRC)/pt_lbvh.hip $(CSRC)/pt_sahdev.hip $(CSRC)/pt_widedev.hip $(CSRC)/pt_comm.hip $(CSRC)/pt_image.cpp $(CSRC)/pt_wide.cpp
-HDRS    := $(CSRC)/pt_internal.hpp $(CSRC)/pt_device.hpp include/pt_api.h
+SRCS    := $(CSRC)/pt_host.cpp $(CSRC)/pt_builder.cpp $(CSRC)/pt_launch.cpp $(CSRC)/pt_obj.cpp $(CSRC)/pt_kernels.hip $(CSRC)/pt_wavefront.hip $(CSRC)/pt_debug.hip $(CSRC)/pt_lbvh.hip $(CSRC)/pt_sahdev.hip $(CSRC)/pt_widedev.hip $(CSRC)/pt_comm.hip $(CSRC)/pt_image.cpp $(CSRC)/pt_wide.cpp
+HDRS    := $(CSRC)/pt_internal.hpp $(CSRC)/pt_context.hpp $(CSRC)/pt_device.hpp include/pt_api.h
 OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 
 $(PKG)/libptamd.so: $(OBJS)
@@ -46,7 +46,7 @@ check-isa: build/isa/pt_kernels.s build/isa/pt_wavefront.s tools/check_isa.py
 # Host-side scene path (pt_add_obj: parallel parse, threaded encounter ranks; pt_upload_triangles: thread pool, parallel SAH
 # top, splice, 4-wide collapse) under ThreadSanitizer and under AddressSanitizer + UBSan, on a generated 200k-triangle OBJ,
 # one context and then two at once.  CPU only (host-only contexts); the device objects are linked in unchanged.
-HOSTSRC := pt_host.cpp pt_obj.cpp pt_wide.cpp pt_image.cpp
+HOSTSRC := pt_host.cpp pt_builder.cpp pt_launch.cpp pt_obj.cpp pt_wide.cpp pt_image.cpp
 DEVOBJ  := build/pt_kernels.hip.o build/pt_wavefront.hip.o build/pt_debug.hip.o build/pt_lbvh.hip.o build/pt_sahdev.hip.o build/pt_widedev.hip.o build/pt_comm.hip.o
 SANFLAGS := -O1 -g -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -Iinclude -I$(CSRC)
 sanitize-host: $(DEVOBJ)

@@ -130,7 +130,7 @@ def kernel_source_sha():
     # device code AND the host code that picks the kernel instance and its launch shape (schedule, pass length, waves per
     # SIMD, node layout): a change in either invalidates counters measured under the old one
     # ... and the builders of the tree the mesh counters are measured on, and the compiler flags
-    for f in ("pt_device.hpp", "pt_kernels.hip", "pt_wavefront.hip", "pt_internal.hpp", "pt_host.cpp", "pt_wide.cpp", "pt_sahdev.hip", "pt_widedev.hip"):
+    for f in ("pt_device.hpp", "pt_kernels.hip", "pt_wavefront.hip", "pt_internal.hpp", "pt_context.hpp", "pt_host.cpp", "pt_builder.cpp", "pt_launch.cpp", "pt_wide.cpp", "pt_sahdev.hip", "pt_widedev.hip"):
         h.update(open(os.path.join(ROOT, "opencl_path_tracer_amd", "csrc", f), "rb").read())
     h.update(open(os.path.join(ROOT, "Makefile"), "rb").read())
     return h.hexdigest()[:16]

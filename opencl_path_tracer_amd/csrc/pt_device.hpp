@@ -290,6 +290,23 @@ struct SceneView {
     unsigned ovf_stride;
 };
 
+struct WorkCount {
+    unsigned nodes, tris;     // per-lane visits / tests
+    unsigned wnodes, wtris;   // wave-level executions of the two bodies (counted by the first active lane)
+    unsigned wshade, wtrips, wrounds;   // wave-level executions of shade_hit, of the segment loop body, of Trav::round
+    unsigned low[6];                    // ... of those that ran for at most 8 lanes: node body, triangle body, its exact part, shade_hit, the
+                                        // big-triangle list's exact tests (all of them in low[5])
+};
+// counting instances: one more execution of body `which` (first active lane only), noting whether it ran for at most 8 lanes
+PT_DEV void count_low(WorkCount* wc, int which) {
+    const unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1 && __popcll(m) <= 8) wc->low[which]++;
+}
+PT_DEV bool first_active_lane() {
+    const unsigned long long m = __ballot(1);
+    return (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1;
+}
+
 // prog.cl:94-112 on one packet; returns t (> 0) or -1.  `limit` is the current closest t: a
 // triangle whose t is clearly larger can neither win nor tie, so it is dropped before the exact
 // (IEEE-divide) evaluation.  Both early-outs are conservative: whatever the exact test would
@@ -302,7 +319,7 @@ struct SceneView {
 //   false: four sign compares first, the reciprocal only for same-sign pairs -- 3 % faster on the
 //          L1/L2 node path, where the 8-clock v_rcp on every test costs more than it saves.
 template <bool QUOT>
-PT_DEV float tri_test(const float4 a, const float4 b, const float4 c, f3 P, f3 Vd, float limit) {
+PT_DEV float tri_test(const float4 a, const float4 b, const float4 c, f3 P, f3 Vd, float limit, WorkCount* wc = nullptr) {
     const f3 r1 = mk(a.x, a.y, a.z), r2 = mk(a.w, b.x, b.y), r3 = mk(b.z, b.w, c.x), N = mk(c.y, c.z, c.w);
     const float num = dot3(r1 - P, N), den = dot3(Vd, N);
     float res = -1.0f;
@@ -315,6 +332,7 @@ PT_DEV float tri_test(const float4 a, const float4 b, const float4 c, f3 P, f3 V
         cand = same_sign && num * __builtin_amdgcn_rcpf(den) <= limit;
     }
     if (cand) {
+        if (wc) { count_low(wc, 2); if (first_active_lane()) wc->low[5]++; }
         const float t = num / den;
         const f3 pt = madd(Vd, t, P);
         const float c1 = dot3(cross3(r2 - r1, pt - r1), N);
@@ -333,16 +351,6 @@ struct LaneStack {
     T* base;        // already offset by the lane
     int stride;     // entries are `stride` elements apart
 };
-
-struct WorkCount {
-    unsigned nodes, tris;     // per-lane visits / tests
-    unsigned wnodes, wtris;   // wave-level executions of the two bodies (counted by the first active lane)
-    unsigned wshade, wtrips, wrounds;   // wave-level executions of shade_hit, of the segment loop body, of Trav::round
-};
-PT_DEV bool first_active_lane() {
-    const unsigned long long m = __ballot(1);
-    return (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1;
-}
 
 enum : int { kVisitLds = 0, kVisitGlobal = 1, kVisitFlat = 2 };      // Trav::node_step
 
@@ -459,7 +467,7 @@ struct Trav {
         const int top = (int)*reinterpret_cast<const StackT*>(tos);
         float ln, lf, rn, rf;
         int li, ri;
-        if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; }
+        if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; count_low(wc, 0); }
         if (KIND == kVisitLds) {
             const char* nb = reinterpret_cast<const char*>(sv.lds_nodes) + (unsigned)cur * (unsigned)kLdsNodeBytes;
             const float2 ex = *reinterpret_cast<const float2*>(nb + onx), xx = *reinterpret_cast<const float2*>(nb + (onx ^ 8));
@@ -572,7 +580,7 @@ struct Trav {
         // access of this visit goes through the checked accessors)
         const bool tight = __ballot(entry_of(tos) + 3 >= sv.lds_entries) != 0;
         const int top = tight ? stack_get(sv, tos) : (int)*reinterpret_cast<const StackT*>(tos);
-        if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; }
+        if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; count_low(wc, 0); }
         const char* nb = reinterpret_cast<const char*>(sv.nodes);
         const unsigned off = (unsigned)cur << 6;
         const float4 h = *reinterpret_cast<const float4*>(nb + off);
@@ -664,7 +672,7 @@ struct Trav {
         // access of this visit goes through the checked accessors)
         const bool tight = __ballot(entry_of(tos) + 3 >= sv.lds_entries) != 0;
         const int top = tight ? stack_get(sv, tos) : (int)*reinterpret_cast<const StackT*>(tos);
-        if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; }
+        if (COUNT) { wc->nodes++; if (first_active_lane()) wc->wnodes++; count_low(wc, 0); }
         const char* nb = reinterpret_cast<const char*>(sv.nodes);
         const unsigned off = (unsigned)cur << 6;
         const float4 h = *reinterpret_cast<const float4*>(nb + off);
@@ -758,8 +766,8 @@ struct Trav {
     }
     template <bool COUNT>
     PT_DEV void tri_update(const SceneView& sv, const float4 a, const float4 b, const float4 c, int ti, WorkCount* wc) {
-        if (COUNT) { wc->tris++; if (first_active_lane()) wc->wtris++; }
-        const float t = tri_test<MODE == kNodesLds>(a, b, c, P, D, best_t * 1.000002f);
+        if (COUNT) { wc->tris++; if (first_active_lane()) wc->wtris++; count_low(wc, 1); }
+        const float t = tri_test<MODE == kNodesLds>(a, b, c, P, D, best_t * 1.000002f, COUNT ? wc : nullptr);
         if (t > 0.0f) {
             bool better = t < best_t;
             if (t == best_t && best >= 0) better = sv.meta[ti].rank < sv.meta[best].rank;
@@ -767,7 +775,7 @@ struct Trav {
         }
     }
 
-    // The big-triangle list (the host keeps walls, floors ... out of the tree: pt_host.cpp build_and_pack), tested
+    // The big-triangle list (the host keeps walls, floors ... out of the tree: pt_builder.cpp build_and_pack), tested
     // at the start of every traversal; what it finds prunes the tree from its first node visit.  Two passes:
     //  1. every lane slab-tests the DISTINCT padded boxes of the listed triangles (the two halves of a wall share
     //     one: 6 boxes for the Cornell box's 12 triangles, grouped by the host) -- a wave-uniform loop at full lane

@@ -1,4 +1,4 @@
-// pt_internal.hpp -- shared between the host side (pt_host.cpp) and the device side
+// pt_internal.hpp -- shared between the host side (pt_host.cpp, pt_builder.cpp, pt_launch.cpp: see pt_context.hpp) and the device side
 // (pt_kernels.hip) of libptamd.so.  Not part of the public ABI (that is include/pt_api.h).
 #pragma once
 

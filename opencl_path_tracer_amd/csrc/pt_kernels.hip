@@ -118,7 +118,7 @@ PT_DEV void render_pixel_lockstep(const RenderParams& p, const SceneView& sv, co
             const int ti = closest_hit<MODE, COUNT>(sv, rP, rD, stk, &t, wc);
             ++*segs;
             if (ti < 0) break;                                       // black environment, prog.cl:367-376
-            if (COUNT && first_active_lane()) wc->wshade++;
+            if (COUNT) { if (first_active_lane()) wc->wshade++; count_low(wc, 3); }
             shade_hit<SK>(rP, rD, st, seed, inside, p, sv.tris, sv.meta, ti, t);
         }
         if (LEAN) fold_sample(p, px.li, st.C(), s);
@@ -197,7 +197,7 @@ PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, con
             } else {
                 ++*segs;
                 if (tr.best >= 0) {
-                    if (COUNT && first_active_lane()) wc->wshade++;
+                    if (COUNT) { if (first_active_lane()) wc->wshade++; count_low(wc, 3); }
                     shade_hit<SK>(rP, rD, st, seed, inside, p, sv.tris, sv.meta, tr.best, tr.best_t);
                     ++bounce;
                     finished = (bounce >= p.iterations);
@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
     wc.wshade = 0;
     wc.wtrips = 0;
     wc.wrounds = 0;
+    for (int i = 0; i < 6; ++i) wc.low[i] = 0;
     const bool lane0 = (threadIdx.x & 63) == 0;
     const bool chained = p.tile_counter != nullptr && p.chunk_spp > 0;
     const int n_pass = chained ? (p.nsamples + p.chunk_spp - 1) / p.chunk_spp : 1;
@@ -362,6 +363,10 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
             stat_add(p, 8, wtr);
             stat_add(p, 9, wro);
         }
+        for (int i = 0; i < 6; ++i) {
+            const unsigned long long v = wave_sum((unsigned long long)wc.low[i]);
+            if (lane0 && p.stats) stat_add(p, 10 + i, v);
+        }
     }
     if (lane0 && p.stats) {
         stat_add(p, 0, segs_tot);
@@ -457,7 +462,7 @@ static hipError_t launch_one(const RenderParams& p, const LaunchConfig& lc, hipS
     constexpr int wpb = BLOCK / 64;
     int blocks = (waves + wpb - 1) / wpb;
     if (p.tile_counter) blocks = std::min(blocks, lc.persistent_blocks);
-    if (p.stack_ovf && (long long)blocks * BLOCK > (long long)p.stack_ovf_lanes) return hipErrorInvalidValue;   // (pt_host.cpp alloc_stack_overflow)
+    if (p.stack_ovf && (long long)blocks * BLOCK > (long long)p.stack_ovf_lanes) return hipErrorInvalidValue;   // (pt_launch.cpp alloc_stack_overflow)
     auto kern = k_render<SPLIT, MODE, BLOCK, COUNT, SCHED, WPS>;
     static LdsMark mark;
     const hipError_t e = ensure_dynamic_lds((const void*)kern, mark, lc.lds_bytes);

@@ -36,7 +36,7 @@ __host__ __device__ __forceinline__ float from_ordered_int(int i) {
     return u.f;
 }
 
-// padded bounds of a triangle: identical arithmetic to padded_bounds() of pt_host.cpp
+// padded bounds of a triangle: identical arithmetic to padded_bounds() of pt_builder.cpp
 __device__ __forceinline__ Box tri_bounds(const pt_triangle& t, bool* finite) {
     Box b;
     float m = 0.f;

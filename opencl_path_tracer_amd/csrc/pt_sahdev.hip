@@ -1,4 +1,4 @@
-// pt_sahdev.hip -- the host builder's binned-SAH tree (BvhBuilder::split, pt_host.cpp), built ON THE DEVICE, node for node.
+// pt_sahdev.hip -- the host builder's binned-SAH tree (BvhBuilder::split, pt_builder.cpp), built ON THE DEVICE, node for node.
 //
 // The reference builds its tree on the host (NodeOnHost::build / convert, main.cpp:195-304); so does this library by
 // default, and its other device builder (pt_lbvh.hip: Morton order + PLOC merges) is quick but renders 0.6-0.8x as fast as
@@ -82,7 +82,7 @@ __device__ __forceinline__ int ordered_int(float f) {
 }
 __device__ __forceinline__ float from_ordered_int(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-// padded_bounds() of pt_host.cpp, the same arithmetic
+// padded_bounds() of pt_builder.cpp, the same arithmetic
 __device__ __forceinline__ PBox tri_bounds(const pt_triangle& t) {
     PBox b;
     float m = 0.f;

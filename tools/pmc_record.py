@@ -4,8 +4,9 @@
   python tools/pmc_record.py cornell_1920x1080_b8_spp64 profiles/counters.json gpurun_out/pmc_cb_*
 
 Per key: VALU instructions per launch, active-lane fraction (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)),
-wave-cycle split, L1 / L2 hit rates, HBM-side bytes per launch (FETCH_SIZE x 2 -- on gfx950 the counter tallies
-128-B requests as 64 B, MI355X_MICROARCH.md -- + WRITE_SIZE, both in KiB), the shader clock during the profiled
+wave-cycle split, L1 / L2 hit rates, fabric-side bytes per launch (FETCH_SIZE x factor + WRITE_SIZE, both in KiB; the factor is
+2 for coalesced streams -- the counter tallies 128-B requests as 64 B, MI355X_MICROARCH.md -- and 1 for the traversal's 64-byte
+gathers, calibrated in profiles/r04/g_*), the shader clock during the profiled
 launches (GRBM_GUI_ACTIVE / 8 XCDs / kernel time) and a hash of the kernel sources they were measured with."""
 import csv
 import glob
@@ -19,7 +20,20 @@ from collections import defaultdict
 sys.path.insert(0, ".")
 from bench import kernel_source_sha  # noqa: E402
 
+args = sys.argv[1:]
+fetch_factor = None
+if "--fetch-factor" in args:
+    i = args.index("--fetch-factor")
+    fetch_factor = float(args[i + 1])
+    del args[i:i + 2]
+sys.argv = [sys.argv[0]] + args
 key, out = sys.argv[1], sys.argv[2]
+# FETCH_SIZE tallies 64 B per request of the L2 towards the fabric (MI355X_MICROARCH.md): a wide coalesced read asks for 128-B
+# lines (x2), the traversal's 64-byte per-lane gathers for 64-B sectors (x1: profiles/r04/g_fetch_size_calibration_64B_gathers.txt).
+# The megakernel on a scene read from global memory is all gathers, on the Cornell box (tree in LDS) all streaming; the wavefront
+# variant streams.  --fetch-factor overrides.
+if fetch_factor is None:
+    fetch_factor = 1.0 if key.startswith("mesh") else 2.0
 wavefront = key.startswith("wavefront")
 vals, durs = defaultdict(list), []
 if wavefront:
@@ -70,7 +84,12 @@ entry = {
     "wave_cycles": {k: c.get(k) for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")},
     "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if "TCC_HIT_sum" in c else None,
     "l1_hit_rate": 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"] if "TCP_TOTAL_CACHE_ACCESSES_sum" in c else None,
-    "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None,
+    "hbm_bytes_per_launch": (fetch_factor * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None,
+    "fetch_size_factor": fetch_factor,
+    "hbm_note": ("L2-miss traffic towards the fabric: FETCH_SIZE x %.0f (calibrated for this access pattern, profiles/r04/g_*) + WRITE_SIZE. "
+                 "Infinity-Cache hits are counted in it: the scene (nodes + packets + meta) is %s" % (
+                     fetch_factor, "72 MB (MESH-1M) / 7 MB (MESH-100k), resident in the 256-MiB Infinity Cache after first touch, so the HBM share is "
+                     "the compulsory part only (scene once + the frame buffers per launch)" if key.startswith("mesh") else "LDS / L2 resident")),
     "fetch_kib_reported": c.get("FETCH_SIZE"), "write_kib": c.get("WRITE_SIZE"),
     "counters": c,
     "kernel_source_sha": kernel_source_sha(),

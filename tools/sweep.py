@@ -32,6 +32,9 @@ def run(W, H, bounces, spp, spec, reps=2, count=False, **opts):
     if count:
         nv, tt, wn, wt = sc.stat("node_visits"), sc.stat("tri_tests"), sc.stat("wave_node_steps"), sc.stat("wave_tri_steps")
         wsegs = segs / 64.0
+        print("   executions for <= 8 lanes: node body %.0f%%, triangle body %.0f%%, its exact part %.0f%% (x%.1f per wave-segment), shade %.0f%%" % (
+            100 * sc.stat("low_node") / max(wn, 1), 100 * sc.stat("low_tri") / max(wt, 1), 100 * sc.stat("low_exact") / max(sc.stat("low_exact_all"), 1),
+            sc.stat("low_exact_all") / wsegs, 100 * sc.stat("low_shade") / max(sc.stat("wave_shade_steps"), 1)))
         print("   per-tile lane balance (lane segments / 64 x busiest lane): %.1f%%" % (100 * segs / max(sc.stat("tile_lane_steps"), 1)))
         extra = "  nodes/seg=%.2f tris/seg=%.2f | per wave-segment: node body x%.1f (util %.0f%%), tri body x%.1f (util %.0f%%), shade x%.2f, trips x%.2f, rounds x%.2f" % (
             nv / segs, tt / segs, wn / wsegs, 100 * nv / (64 * wn), wt / wsegs, 100 * tt / (64 * wt),
