@@ -380,11 +380,14 @@ static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsa
         }
     if (!ctx->wf_event[0]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->wf_event[0], hipEventDisableTiming));
     WfParams w[kWfMaxChains];
+    // contiguous chains of whole 8,192-pixel units (dealing the frame out in interleaved blocks of 8 rows, so that every chain gets
+    // its share of the cheap and the expensive parts, measured the same on the Cornell box and 30 % slower on MESH-1M, whose rays
+    // then cover the whole mesh in every chain: profiles/r04/f_*)
     const int64_t unit = 8192;
     const int64_t per = ((ctx->npix + chains - 1) / chains + unit - 1) / unit * unit;
     for (int c = 0; c < chains; ++c) {
         WfParams& wc = w[c];
-        const int64_t p0 = std::min<int64_t>((int64_t)c * per, ctx->npix), p1 = std::min<int64_t>(p0 + per, ctx->npix);
+        const int64_t p0 = std::min<int64_t>((int64_t)c * per, ctx->npix), count = std::min<int64_t>(p0 + per, ctx->npix) - p0;
         wc.rp = rp;
         if (rp.stack_ovf) wc.rp.stack_ovf = rp.stack_ovf + (size_t)c * chain_lanes;      // (stack_ovf_lanes stays the stride between entries)
         wc.sP = reinterpret_cast<float*>(ctx->d_wf_state);        // kWfFields x np x 12 B <= 4 x np x 16 B, indexed by local pixel
@@ -398,7 +401,7 @@ static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsa
         wc.hit[1] = reinterpret_cast<float2*>(ctx->d_wf_state + 12 * np) + np + p0;
         for (int k = 0; k < 3; ++k) wc.q_cls[k] = ctx->d_wf_queues + (size_t)k * np + p0;
         wc.counters = ctx->d_wf_counters + (size_t)c * kCounterWords;
-        wc.npix = (int32_t)(p1 - p0);
+        wc.npix = (int32_t)count;
         wc.pix0 = (int32_t)p0;
         wc.npix_all = (int32_t)ctx->npix;
         wc.n_cbox = ctx->cost_binning ? (int32_t)(ctx->cost_boxes.size() / 6) : 0;

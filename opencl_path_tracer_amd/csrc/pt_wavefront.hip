@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(kWfGenBlock) wf_generate(WfParams w) {
 #endif
 constexpr int kWfRaysPerWave = PT_WF_RPW;
 constexpr int kWfRaysPerWaveLds = PT_WF_RPW_LDS;      // the 768-thread instance (whole tree in LDS)
-constexpr int kWfSuspendLanes = 48;     // 8 / 16 / 32 / 48 -> 749 / 752 / 763 / 773 Msamples/s (flat loop 700)
+constexpr int kWfSuspendLanes = 48;     // (round 4, with the phase switching of Trav::round: 24 / 36 / 48 / 56 all within 1 %)     // 8 / 16 / 32 / 48 -> 749 / 752 / 763 / 773 Msamples/s (flat loop 700)
 
 // Traversal with lane refill: a trip = while-while rounds until most lanes are done; a lane whose ray is
 // finished takes the next ray of the wave's range before the next trip (the next ray's 32 B are prefetched one

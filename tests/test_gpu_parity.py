@@ -1262,3 +1262,33 @@ def test_lost_hand_over_becomes_an_error_not_a_hang(api, cb_spec):
     sc.render(8)
     assert same_bits(sc.read_colors(), want_c) and np.array_equal(sc.read_rnds(), want_r)
     assert sc.stat("samples") >= W * H * 8
+
+
+def test_wavefront_chains_render_the_same_frame(api, cb_spec):
+    """The wavefront variant cuts the local pixels into chains that run on HIP streams of their own (option wf_streams, default
+    4 for frames of >= 262,144 pixels): every chain has its slice of the ray / hit streams and queues and its own counters.
+    One, two, three and four chains -- and the megakernel, which the oracle tests pin -- must give the same bits, for the tree
+    in LDS and for 4-wide nodes from global memory (whose stack overflow ranges are per chain too)."""
+    from opencl_path_tracer_amd import scenes
+    W, H = 704, 400                                        # 281,600 pixels: four chains
+    for spec, pre, bounces in ((cb_spec, {}, 6), (scenes.displaced_grid_mesh(6000), {"wide_nodes": 2, "wide_lds_entries": 6}, 5)):
+        ref = api.Scene(W, H)
+        for k, v in pre.items():
+            ref.set_option(k, v)
+        ref.load(spec)
+        ref.iterations = bounces
+        ref.render(3)
+        want_c, want_r = ref.read_colors(), ref.read_rnds()
+        for chains in (1, 2, 3, 4):
+            sc = api.Scene(W, H)
+            for k, v in pre.items():
+                sc.set_option(k, v)
+            sc.load(spec)
+            sc.iterations = bounces
+            sc.set_option("variant", 1)
+            sc.set_option("wf_streams", chains)
+            sc.render(2)
+            sc.render(1)
+            assert same_bits(sc.read_colors(), want_c) and np.array_equal(sc.read_rnds(), want_r), (spec.name, chains)
+            sc.close()
+        ref.close()

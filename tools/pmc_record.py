@@ -37,6 +37,8 @@ if fetch_factor is None:
 wavefront = key.startswith("wavefront")
 vals, durs = defaultdict(list), []
 if wavefront:
+    # (profile it with wf_streams=1: one chain, so that a wf_generate launch IS a sample pass of the whole frame; under the
+    # profiler the kernels of several chains are serialised anyway)
     # the wavefront variant: a "launch" is one sample pass = wf_generate + iterations x (wf_intersect + wf_shade); counters
     # and kernel time are summed over all of them and divided by the number of passes (= wf_generate launches) of the run
     tot, npass, tdur = defaultdict(float), defaultdict(int), defaultdict(float)
