@@ -279,11 +279,13 @@ static int auto_chunk_spp(int n_tiles, int resident_waves, int nsamples) {
 
 static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc) {
     // whole tree in LDS: two 768-thread workgroups per CU (six waves per SIMD) if their LDS fits, else two of 512
-    // -- and if the launch has a tile for each of their waves: with fewer (a 1080p frame over 8 GPUs: 4,050 tiles for
-    // 6,144 waves) the extra waves stay empty and the 128-VGPR instance runs each tile faster (profiles/r03/g_*)
+    // -- and if the launch has at least TWO tiles for each of their waves: with fewer (a 1080p frame over 4 / 8 GPUs: 8,160 /
+    // 4,080 tiles for 6,144 waves) the 128-VGPR instance, whose waves run each tile faster, wins (round 4, with the phase
+    // switching: a rank of 4 6,806 against 6,515 Msamples/s whole job, a rank of 8 9,211 against 8,524; a rank of 2 -- 16,080
+    // tiles -- 4,228 / 4,246 either way; profiles/r04/i_*)
     const bool wide_fits = p.node_mode == kNodesLds && 2 * (traversal_lds_bytes(p, kLdsBlockWide) + 512) <= kLdsPerCu;
     const bool wide_block = wide_fits && ctx->lds_block != kLdsBlockBase &&
-                            (ctx->lds_block == kLdsBlockWide || p.n_tiles >= ctx->cu_count * 2 * (kLdsBlockWide / 64));
+                            (ctx->lds_block == kLdsBlockWide || p.n_tiles >= 2 * ctx->cu_count * 2 * (kLdsBlockWide / 64));
     lc->block = traversal_block(p.node_mode, wide_block);
     lc->lds_bytes = traversal_lds_bytes(p, lc->block);
     lc->count_work = ctx->count_work != 0;

@@ -288,8 +288,9 @@ def test_launch_plan_of_a_rank_of_eight(api, cb_spec):
     """The launch policy DESIGN.md section 6 states, pinned: on a 256-CU device a one-GPU 1080p Cornell frame takes the six-wave
     768-thread instance under the suspend schedule with passes of 32 samples (64 from 256 spp per launch); the rank of an 8-GPU job
     has 4,050 tiles for the 6,144 waves that instance would keep resident, so it gets the 512-thread instance, lockstep, whole
-    tiles -- the measured-best shape for one tile per wave (profiles/r03/g_*); ranks of 2 / 4 keep the wide instance in lockstep
-    with passes of 8, and so does a rank of a 4K frame over 8 (16,320 tiles)."""
+    tiles -- the measured-best shape for one tile per wave (profiles/r03/g_*, r04/i_*); so does a rank of 4 (8,160 tiles: fewer
+    than two per wave of the wide instance), with passes of 8; a rank of 2 and a rank of a 4K frame over 8 (16,080 / 16,320 tiles)
+    keep the wide instance in lockstep with passes of 8."""
     def plan(W, H, rank, world, nsamples=64):
         sc = api.Scene(W, H, device=None, rank=rank, world=world, rows_per_block=8).load(cb_spec)
         return sc.debug_launch_plan(nsamples, 256)
@@ -302,7 +303,7 @@ def test_launch_plan_of_a_rank_of_eight(api, cb_spec):
         assert 3840 <= p8["tiles"] <= 4080 and p8["resident_waves"] == 4096 and p8["node_mode"] == 0
     p2, p4 = plan(1920, 1080, 1, 2), plan(1920, 1080, 2, 4)
     assert (p2["block"], p2["schedule"], p2["chunk_spp"]) == (768, 0, 8), p2
-    assert (p4["block"], p4["schedule"], p4["chunk_spp"]) == (768, 0, 8), p4
+    assert (p4["block"], p4["waves_per_simd"], p4["schedule"], p4["chunk_spp"]) == (512, 4, 0, 8), p4
     k8 = plan(3840, 2160, 5, 8)             # 16,320 tiles: 2.7 per resident wave
     assert (k8["block"], k8["waves_per_simd"], k8["schedule"], k8["chunk_spp"]) == (768, 6, 0, 8), k8
 
