@@ -31,8 +31,8 @@ while [ $# -gt 0 ]; do
     pmc) # the PMC passes behind profiles/counters.json (one counter set per pass; never with the runtime traces)
         rm -f gpurun_out/counters.json; cp profiles/counters.json gpurun_out/counters.json 2>/dev/null
         tools/pmc_passes.sh ${tag}_cb scene=cornell spp=64 reps=2 > $out/pmc_cb.log 2>&1 && python3 tools/pmc_record.py cornell_1920x1080_b8_spp64 gpurun_out/counters.json gpurun_out/pmc_${tag}_cb_[0-9] > $out/pmc_cb_record.log 2>&1; tail -24 $out/pmc_cb_record.log
-        tools/pmc_passes.sh ${tag}_mesh100k scene=mesh100k spp=16 reps=2 > $out/pmc_mesh100k.log 2>&1 && python3 tools/pmc_record.py mesh100k_1920x1080_b8_spp16 gpurun_out/counters.json gpurun_out/pmc_${tag}_mesh100k_[0-9] > $out/pmc_mesh100k_record.log 2>&1; tail -24 $out/pmc_mesh100k_record.log
-        tools/pmc_passes.sh ${tag}_mesh1m scene=mesh1m spp=8 bounces=16 reps=2 > $out/pmc_mesh1m.log 2>&1 && python3 tools/pmc_record.py mesh1m_1920x1080_b16_spp8 gpurun_out/counters.json gpurun_out/pmc_${tag}_mesh1m_[0-9] > $out/pmc_mesh1m_record.log 2>&1; tail -24 $out/pmc_mesh1m_record.log
+        tools/pmc_passes.sh ${tag}_mesh100k scene=mesh100k spp=64 reps=2 > $out/pmc_mesh100k.log 2>&1 && python3 tools/pmc_record.py mesh100k_1920x1080_b8_spp64 gpurun_out/counters.json gpurun_out/pmc_${tag}_mesh100k_[0-9] > $out/pmc_mesh100k_record.log 2>&1; tail -24 $out/pmc_mesh100k_record.log
+        tools/pmc_passes.sh ${tag}_mesh1m scene=mesh1m spp=64 bounces=16 reps=2 > $out/pmc_mesh1m.log 2>&1 && python3 tools/pmc_record.py mesh1m_1920x1080_b16_spp64 gpurun_out/counters.json gpurun_out/pmc_${tag}_mesh1m_[0-9] > $out/pmc_mesh1m_record.log 2>&1; tail -24 $out/pmc_mesh1m_record.log
         tools/pmc_passes.sh ${tag}_wf scene=cornell spp=4 reps=2 variant=1 wf_streams=1 > $out/pmc_wf.log 2>&1 && python3 tools/pmc_record.py wavefront_cornell_1920x1080_b8_spp1 gpurun_out/counters.json gpurun_out/pmc_${tag}_wf_[0-9] > $out/pmc_wf_record.log 2>&1; tail -24 $out/pmc_wf_record.log;;
     sweep) timeout -k 10 600 python tools/sweep.py --count --what cb,c1c4,mesh100k,mesh1m > $out/sweep_all.txt 2>&1; grep -v "^$" $out/sweep_all.txt | cut -c1-330;;
   esac
