@@ -93,7 +93,7 @@ struct pt_context {
     uint32_t* d_wf_counters = nullptr;   // kWfMaxChains x (kWfMaxBounces + 4) rows
     hipStream_t wf_stream[kWfMaxChains] = {};   // chains 1.. of the wavefront variant (chain 0 runs on `stream`)
     hipEvent_t wf_event[kWfMaxChains] = {};
-    int poll_timeout_ms = 2000;          // chained passes: a wave gives a tile's previous pass this long before it reports the hand-over lost
+    int poll_timeout_ms = 10000;         // chained passes: a wave gives a tile's previous pass this long before it reports the hand-over lost
     int debug_stall_tile = -1;           // tests: pass 0 of this tile is never published
     bool counters_suspect = false;
     bool launched_since_check = false;   // a persistent launch has been enqueued since the work counter's error word was last read       // a launch failed or lost a hand-over: word 0 / 1 of d_tile_counter may not be back at zero

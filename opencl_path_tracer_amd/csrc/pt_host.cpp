@@ -188,8 +188,8 @@ int pt_create_tiled(int device, int32_t width, int32_t height, int32_t rank, int
     if ((e = hipMalloc((void**)&ctx->d_rnds, sizeof(int32_t) * np)) != hipSuccess) return bail("hipMalloc(rnds)", e);     // main.cpp:509
     if ((e = hipMalloc((void**)&ctx->d_colors, sizeof(float4) * nslab)) != hipSuccess) return bail("hipMalloc(colors)", e);  // main.cpp:520
     if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatCols * kStatRows)) != hipSuccess) return bail("hipMalloc(stats)", e);
-    if ((e = hipMalloc((void**)&ctx->d_tile_counter, 64)) != hipSuccess) return bail("hipMalloc(tile counter)", e);
-    if ((e = hipMemset(ctx->d_tile_counter, 0, 64)) != hipSuccess) return bail("hipMemset", e);      // zeroed ONCE: the last wave of a launch leaves it zero (k_render)
+    if ((e = hipMalloc((void**)&ctx->d_tile_counter, sizeof(uint32_t) * kTileCounterWords)) != hipSuccess) return bail("hipMalloc(tile counter)", e);
+    if ((e = hipMemset(ctx->d_tile_counter, 0, sizeof(uint32_t) * kTileCounterWords)) != hipSuccess) return bail("hipMemset", e);      // zeroed ONCE: the last wave of a launch leaves it zero (k_render)
     if ((e = hipMemset(ctx->d_rays, 0, sizeof(pt_ray) * np)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->d_colors, 0, sizeof(float4) * nslab)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->d_stats, 0, sizeof(unsigned long long) * kStatCols * kStatRows)) != hipSuccess) return bail("hipMemset", e);

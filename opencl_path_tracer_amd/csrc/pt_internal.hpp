@@ -70,7 +70,10 @@ constexpr int64_t kMaxTriangles = (int64_t)1 << 26;
 constexpr int64_t kDeviceBuildFrom = 16384;   // SAH trees of scenes this big are built on the device by default (same tree; mesh6k: 2.4 vs 2.8 ms, 1M: 15 vs 99)
 constexpr int kMaxLeaf = 4;        // triangles per leaf (<= 8 by the reference encoding)
 constexpr int kMaxDepth = 30;      // builder guarantees depth <= kMaxDepth
-constexpr int kTileCounterError = 4;   // word of RenderParams::tile_counter that holds 1 + tile of a lost hand-over (word 5: the pass)
+constexpr int kTileCounterError = 16;  // word of RenderParams::tile_counter that holds 1 + tile of a lost hand-over (word 17: the pass) -- on a cache
+                                       // line of its own: the waves that poll for a hand-over look at it now and then, and the line of words 0 / 1
+                                       // takes every work-item fetch of the launch
+constexpr int kTileCounterWords = 32;  // words of the work counter (two 64-byte lines)
 constexpr int kStatRows = 256;     // statistics counters are spread over this many rows of kStatCols
 constexpr int kStatCols = 16;
 // k_render instances whose register budget is set for this many waves per SIMD or more carry nothing across a traversal
@@ -125,7 +128,7 @@ struct RenderParams {
     uint32_t* stack_ovf;         // kNodesWide: [entries past the LDS part][lane of the grid], or null when LDS holds the worst case
     int32_t stack_ovf_lanes;     // lanes stack_ovf has room for (every launch's grid must fit)
     uint32_t* tile_counter;      // != 0: persistent launch, waves pull tile indices from word 0; word 1 counts the waves that left (the last resets
-                                 // both); words 4 / 5: 1 + tile and pass of a hand-over that never came (kTileCounterError), left for the host
+                                 // both); words 16 / 17: 1 + tile and pass of a hand-over that never came (kTileCounterError), left for the host
     uint32_t poll_ticks;         // chained passes: how long a wave waits for a tile's previous pass, in 10-ns ticks of s_memrealtime, before it
                                  // reports the tile in word 4 and the launch winds down (pt_sync then returns PT_EHIP)
     int32_t debug_stall_tile;    // tests: pass 0 of this tile is rendered but never published (-1: none)

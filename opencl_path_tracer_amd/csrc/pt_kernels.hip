@@ -281,24 +281,27 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
                 // item) or the launch is already winding down.  The poll is therefore BOUNDED: after poll_ticks (2 s by default) the
                 // wave reports the tile in tile_counter[kTileCounterError] and leaves; every other waiting wave sees that word and
                 // leaves too, the launch drains, and the host turns the word into PT_EHIP (pt_sync) instead of a hung process.
-                unsigned seen = 0, lost = 0;
+                unsigned seen = 0, lost = 0, polls = 0;
                 const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
                 for (;;) {
-                    if (lane0) {
-                        seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        lost = __hip_atomic_load(&p.tile_counter[kTileCounterError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    if (lane0) seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
-                    lost = (unsigned)__builtin_amdgcn_readfirstlane((int)lost);
-                    if (seen >= (unsigned)pass || lost != 0) break;
-                    if (__builtin_amdgcn_s_memrealtime() - w0 > (unsigned long long)p.poll_ticks) {
-                        // (tile and pass in ONE 8-byte compare-and-swap: the first wave to give up names them)
-                        const unsigned long long mine = ((unsigned long long)(unsigned)pass << 32) | (unsigned long long)((unsigned)tile + 1u);
-                        unsigned long long was = 0;
-                        if (lane0) was = atomicCAS(reinterpret_cast<unsigned long long*>(&p.tile_counter[kTileCounterError]), 0ull, mine);
-                        const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)was);
-                        lost = first != 0 ? first : (unsigned)tile + 1u;
-                        break;
+                    if (seen >= (unsigned)pass) break;
+                    // now and then (every 64th poll: thousands of waves poll at once, and one word read by all of them every
+                    // microsecond is a hot spot of its own): has another wave given up, or is it time to?
+                    if ((++polls & 63u) == 0) {
+                        if (lane0) lost = __hip_atomic_load(&p.tile_counter[kTileCounterError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lost = (unsigned)__builtin_amdgcn_readfirstlane((int)lost);
+                        if (lost != 0) break;
+                        if (__builtin_amdgcn_s_memrealtime() - w0 > (unsigned long long)p.poll_ticks) {
+                            // (tile and pass in ONE 8-byte compare-and-swap: the first wave to give up names them)
+                            const unsigned long long mine = ((unsigned long long)(unsigned)pass << 32) | (unsigned long long)((unsigned)tile + 1u);
+                            unsigned long long was = 0;
+                            if (lane0) was = atomicCAS(reinterpret_cast<unsigned long long*>(&p.tile_counter[kTileCounterError]), 0ull, mine);
+                            const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)was);
+                            lost = first != 0 ? first : (unsigned)tile + 1u;
+                            break;
+                        }
                     }
                     __builtin_amdgcn_s_sleep(8);
                 }

@@ -235,11 +235,11 @@ int sync_and_check(pt_context* ctx) {
     }
     if (!ctx->launched_since_check || !ctx->d_tile_counter) return PT_OK;
     ctx->launched_since_check = false;
-    uint32_t words[8] = {};
+    uint32_t words[kTileCounterWords] = {};
     PT_HIP(ctx, hipMemcpy(words, ctx->d_tile_counter, sizeof words, hipMemcpyDeviceToHost));
     if (words[kTileCounterError] != 0) {
         ctx->counters_suspect = true;
-        PT_HIP(ctx, hipMemset(ctx->d_tile_counter, 0, 64));
+        PT_HIP(ctx, hipMemset(ctx->d_tile_counter, 0, sizeof words));
         ctx->counters_suspect = false;
         char msg[256];
         std::snprintf(msg, sizeof msg, "k_render: pass %u of tile %u waited more than %d ms for the tile's previous pass to be handed over (the "
@@ -259,7 +259,7 @@ extern "C" {
 // failed synchronize, a lost hand-over -- sets counters_suspect, and the next launch clears the counter first.
 static int prepare_work_counter(pt_context* ctx) {
     if (ctx->counters_suspect) {
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counter, 0, 64, ctx->stream));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counter, 0, sizeof(uint32_t) * kTileCounterWords, ctx->stream));
         ctx->counters_suspect = false;
     }
     ctx->launched_since_check = true;
