@@ -90,10 +90,6 @@ struct pt_context {
     float4* d_wf_state = nullptr;   // per local pixel: 4 float4 worth of path factors + colour (5 x 12 B), 8 + 4 float4 of ray streams (rsA, rsB; rsC), 2 float2 of hits
     int32_t* d_wf_queues = nullptr; // 3 x npix int32 (class queues)
     std::vector<float> cost_boxes;  // 6 floats per complex object (wavefront cost classes)
-    int wf_sort = -1;                    // option wf_sort: rays of bounce >= 1 taken in sorted order (octant, start triangle); -1 default (off)
-    uint32_t* d_wf_sort = nullptr;       // 4 x npix words (keys, keys', positions, permutation), sliced by chain like the streams
-    void* d_wf_sort_temp[kWfMaxChains] = {};
-    size_t wf_sort_temp_bytes = 0;
     uint32_t* d_wf_counters = nullptr;   // kWfMaxChains x (kWfMaxBounces + 4) rows
     hipStream_t wf_stream[kWfMaxChains] = {};   // chains 1.. of the wavefront variant (chain 0 runs on `stream`)
     hipEvent_t wf_event[kWfMaxChains] = {};

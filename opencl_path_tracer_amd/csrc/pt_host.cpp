@@ -228,9 +228,6 @@ void pt_destroy(pt_context* ctx) {
         if (ctx->d_wf_state) (void)hipFree(ctx->d_wf_state);
         if (ctx->d_wf_queues) (void)hipFree(ctx->d_wf_queues);
         if (ctx->d_wf_counters) (void)hipFree(ctx->d_wf_counters);
-        if (ctx->d_wf_sort) (void)hipFree(ctx->d_wf_sort);
-        for (int c = 0; c < kWfMaxChains; ++c)
-            if (ctx->d_wf_sort_temp[c]) (void)hipFree(ctx->d_wf_sort_temp[c]);
         for (int c = 0; c < kWfMaxChains; ++c) {
             if (ctx->wf_stream[c]) (void)hipStreamDestroy(ctx->wf_stream[c]);
             if (ctx->wf_event[c]) (void)hipEventDestroy(ctx->wf_event[c]);
@@ -527,9 +524,6 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "debug_stall_tile") {
         if (value < -1 || value > 0x7fffffff) return fail(ctx, PT_EINVAL, "debug_stall_tile: -1 none, or a tile index");
         ctx->debug_stall_tile = (int)value;
-    } else if (k == "wf_sort") {
-        if (value < -1 || value > 1) return fail(ctx, PT_EINVAL, "wf_sort: -1 default, 0 off, 1 on");
-        ctx->wf_sort = (int)value;
     } else if (k == "wf_streams") {
         if (value < -1 || value == 0 || value > kWfMaxChains) return fail(ctx, PT_EINVAL, "wf_streams: -1 default, 1..8");
         ctx->wf_streams = (int)value;

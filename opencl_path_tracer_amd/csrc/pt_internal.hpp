@@ -185,12 +185,6 @@ struct WfParams {
     int32_t pix0;          // first local pixel of the chain
     int32_t npix_all;      // local pixels of the context (stride of sP's fields)
     int32_t sample;        // current_sample of this pass
-    // ray reorder (option wf_sort; cost class 0 only): wf_shade leaves a sort key per continuing ray -- direction octant above the
-    // index of the triangle it starts on (leaf order = a walk through space) --, the host sorts (key, stream position) pairs between
-    // wf_shade and wf_intersect, and wf_intersect takes its rays in sorted order THROUGH the permutation (the streams stay where they are)
-    uint32_t* sort_keys;   // written by wf_shade for the NEXT bounce's stream (nullptr: off)
-    const uint32_t* perm;  // read by wf_intersect: stream position of the i-th ray in sorted order (nullptr: stream order)
-    int32_t key_shift;     // bits of a triangle index
 };
 
 // device-side BVH construction (pt_lbvh.hip); all pointers are device memory owned by the caller
@@ -299,9 +293,6 @@ hipError_t launch_filt_im(const float4* colors, float4* out, int32_t width, int3
 hipError_t launch_wf_generate(const WfParams& p, hipStream_t stream);
 hipError_t launch_wf_intersect(const WfParams& p, int bounce, int cu_count, hipStream_t stream);
 hipError_t launch_wf_shade(const WfParams& p, int bounce, hipStream_t stream);
-// sorts the class-0 stream of `bounce` (filled by the wf_shade launch before): p.sort_keys -> perm_out; idx / keys_alt / temp: scratch
-size_t wf_sort_temp_bytes(int n, int end_bit);
-hipError_t launch_wf_sort(const WfParams& p, int bounce, uint32_t* idx, uint32_t* keys_alt, uint32_t* perm_out, void* temp, size_t temp_bytes, hipStream_t stream);
 hipError_t launch_debug_closest_hit(const RenderParams& p, const pt_ray* rays, int64_t n, float* out_t, int32_t* out_tri, int cu_count, hipStream_t stream);
 
 }  // namespace ptamd

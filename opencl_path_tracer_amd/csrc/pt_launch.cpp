@@ -368,10 +368,6 @@ static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsa
         PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_counters, sizeof(uint32_t) * kCounterWords * kWfMaxChains));
     }
     if (ctx->npix == 0) return PT_OK;
-    const bool sorting = ctx->wf_sort > 0 && rp.n_tris > 0;
-    int key_shift = 1;
-    while ((1ll << key_shift) < (long long)rp.n_tris && key_shift < 29) ++key_shift;
-    if (sorting && !ctx->d_wf_sort) PT_HIP(ctx, hipMalloc((void**)&ctx->d_wf_sort, sizeof(uint32_t) * 4 * np));
     // chains of whole 8,192-pixel units, at least ~64k pixels each (a chain of a few thousand rays is all launch overhead)
     const int want = ctx->wf_streams > 0 ? ctx->wf_streams : kWfDefaultChains;
     int chains = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, kWfMaxChains), ctx->npix / 65536));
@@ -407,26 +403,12 @@ static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsa
         wc.hit[1] = reinterpret_cast<float2*>(ctx->d_wf_state + 12 * np) + np + p0;
         for (int k = 0; k < 3; ++k) wc.q_cls[k] = ctx->d_wf_queues + (size_t)k * np + p0;
         wc.counters = ctx->d_wf_counters + (size_t)c * kCounterWords;
-        wc.sort_keys = sorting ? ctx->d_wf_sort + p0 : nullptr;
-        wc.perm = nullptr;
-        wc.key_shift = key_shift;
         wc.npix = (int32_t)count;
         wc.pix0 = (int32_t)p0;
         wc.npix_all = (int32_t)ctx->npix;
         wc.n_cbox = ctx->cost_binning ? (int32_t)(ctx->cost_boxes.size() / 6) : 0;
         for (int b = 0; b < wc.n_cbox; ++b)
             for (int k = 0; k < 6; ++k) wc.cbox[b][k] = ctx->cost_boxes[(size_t)b * 6 + k];
-    }
-    if (sorting) {
-        const size_t need = wf_sort_temp_bytes((int)per, std::min(32, key_shift + 3));
-        for (int c = 0; c < chains; ++c)
-            if (!ctx->d_wf_sort_temp[c] || ctx->wf_sort_temp_bytes < need) {
-                PT_HIP(ctx, hipDeviceSynchronize());
-                if (ctx->d_wf_sort_temp[c]) PT_HIP(ctx, hipFree(ctx->d_wf_sort_temp[c]));
-                ctx->d_wf_sort_temp[c] = nullptr;
-                PT_HIP(ctx, hipMalloc(&ctx->d_wf_sort_temp[c], std::max<size_t>(need, 256)));
-            }
-        ctx->wf_sort_temp_bytes = std::max(ctx->wf_sort_temp_bytes, need);
     }
     // the other chains' streams start behind whatever the context's stream holds, and the context's stream ends behind them
     PT_HIP(ctx, hipEventRecord(ctx->wf_event[0], ctx->stream));
@@ -446,13 +428,9 @@ static int render_wavefront(pt_context* ctx, const RenderParams& rp, int32_t nsa
                 EventPair* ep = nullptr;
                 int rc = PT_OK;
                 if (c == 0 && (rc = time_begin(ctx, &ep)) != PT_OK) return rc;      // kernel_ms: wf_intersect of chain 0 (the others overlap it)
-                uint32_t* const sort_base = sorting ? ctx->d_wf_sort + (size_t)w[c].pix0 : nullptr;      // this chain's slice of [keys | keys' | positions | permutation]
-                w[c].perm = (sorting && b > 0) ? sort_base + 3 * np : nullptr;
                 PT_HIP(ctx, launch_wf_intersect(w[c], b, ctx->cu_count, st));
                 if (c == 0 && (rc = time_end(ctx, ep)) != PT_OK) return rc;
                 PT_HIP(ctx, launch_wf_shade(w[c], b, st));
-                if (sorting && b + 1 < rp.iterations)
-                    PT_HIP(ctx, launch_wf_sort(w[c], b + 1, sort_base + 2 * np, sort_base + np, sort_base + 3 * np, ctx->d_wf_sort_temp[c], ctx->wf_sort_temp_bytes, st));
             }
         if (ctx->timing && ctx->events_used >= 4096) {   // bound the event pool
             int rc = time_collect(ctx);

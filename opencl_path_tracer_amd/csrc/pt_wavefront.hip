@@ -1,6 +1,5 @@
 // pt_wavefront.hip -- the stream-compacted ("wavefront") formulation of the same path
 // (BASELINE north_star; option variant = 1).  Device helpers: pt_device.hpp.
-#include <hipcub/hipcub.hpp>
 #include "pt_device.hpp"
 
 #include <algorithm>
@@ -265,7 +264,6 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
     const float4* __restrict__ rsA = w.rsA[bounce & 1][cost];
     const float4* __restrict__ rsB = w.rsB[bounce & 1][cost];
     float2* __restrict__ hits = w.hit[cost];
-    const uint32_t* __restrict__ perm = cost == 0 ? w.perm : nullptr;      // wave-uniform: sorted order -> stream position (wf_sort)
     const unsigned long long lt = lanemask_lt();
     // wave-uniform loop state (wave index, the cursor cbase / cend of the wave's ray range) is kept in scalar registers
     // -- readfirstlane at every redefinition -- so that it can never be spilled lane by lane under a partial exec mask
@@ -314,9 +312,8 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
                         const float s_bt = tr.best_t;
                         const int s_b = tr.best, s_cur = tr.cur, s_pend = tr.pend;
                         char* const s_tos = tr.tos;
-                        const unsigned ri = cbase + (threadIdx.x & 63);
-                        if (ri < cend) {
-                            const unsigned r = perm ? perm[ri] : ri;
+                        const unsigned r = cbase + (threadIdx.x & 63);
+                        if (r < cend) {
                             const float4 A = rsA[r];
                             const float2 Bq = *reinterpret_cast<const float2*>(&rsB[r]);
                             tr.setup(mk(A.x, A.y, A.z), mk(A.w, Bq.x, Bq.y));
@@ -353,10 +350,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
                 const unsigned my = cbase + (unsigned)__popcll(want & lt);
                 if (npos == ~0u && my < cend) {
                     npos = my;
-                    const unsigned src = perm ? perm[my] : my;
-                    nA = rsA[src];
-                    nB = *reinterpret_cast<const float2*>(&rsB[src]);
-                    if (sv.n_flat > 0) nH = hits[src];
+                    nA = rsA[my];
+                    nB = *reinterpret_cast<const float2*>(&rsB[my]);
+                    if (sv.n_flat > 0) nH = hits[my];
                 }
                 cbase = (unsigned)__builtin_amdgcn_readfirstlane((int)min(cbase + (unsigned)__popcll(want), cend));
             }
@@ -376,7 +372,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
             }
             // ---- finished: hit record + class byte
             if (tr.done() && pos != ~0u) {
-                hits[perm ? perm[pos] : pos] = make_float2(tr.best_t, __int_as_float(tr.best));
+                hits[pos] = make_float2(tr.best_t, __int_as_float(tr.best));
                 int cls = 2;
                 if (tr.best >= 0) {
                     const int type = p.mats[sv.meta[tr.best].mati].type;
@@ -413,7 +409,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) wf_intersect(WfParams w, int bounc
 #pragma unroll
         for (int k = 0; k < RPB / BLOCK; ++k) {
             const unsigned r = k * BLOCK + threadIdx.x;
-            if (cl[k] >= 0) w.q_cls[cl[k]][lds_base[cl[k]] + lds_cnt[(r >> 6) * 3 + cl[k]] + off[k]] = (int)(((unsigned)cost << 31) | (perm ? perm[block_base + r] : block_base + r));
+            if (cl[k] >= 0) w.q_cls[cl[k]][lds_base[cl[k]] + lds_cnt[(r >> 6) * 3 + cl[k]] + off[k]] = (int)(((unsigned)cost << 31) | (block_base + r));
         }
         if (wave == 0) {            // (the fetched range is wave-uniform state: through scalar registers, as everywhere)
             unsigned t = 0;
@@ -442,12 +438,10 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
     unsigned flags[kWfShadePerThread];
     int seeds[kWfShadePerThread];
     f3 rP[kWfShadePerThread], rD[kWfShadePerThread], fLs[kWfShadePerThread];
-    int tis[kWfShadePerThread];                           // the triangle the continuing ray starts on (wf_sort)
 #pragma unroll
     for (int k = 0; k < kWfShadePerThread; ++k) {
         const unsigned i = (blockIdx.x * kWfShadePerThread + k) * kWfShadeBlock + threadIdx.x;
         li[k] = 0;
-        tis[k] = 0;
         cost[k] = -1;
         flags[k] = 0;
         seeds[k] = 0;
@@ -474,7 +468,6 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
                 rP[k] = mk(A.x, A.y, A.z);
                 rD[k] = mk(A.w, B.x, B.y);
                 bool inside = (st.flags & (unsigned)kWfInsideBit) != 0;
-                tis[k] = __float_as_int(h.y);
                 shade_hit<false>(rP[k], rD[k], st, seed, inside, p, p.tris, p.meta, __float_as_int(h.y), h.x);
                 if (bounce + 1 >= p.iterations) {
                     wf_finalize(w, li[k], st.C());
@@ -496,35 +489,7 @@ __global__ void __launch_bounds__(kWfShadeBlock) wf_shade(WfParams w, int bounce
             w.rsA[(bounce + 1) & 1][cost[k]][npos[k]] = make_float4(rP[k].x, rP[k].y, rP[k].z, rD[k].x);
             w.rsB[(bounce + 1) & 1][cost[k]][npos[k]] = make_float4(rD[k].y, rD[k].z, __int_as_float(li[k]), __int_as_float((int)flags[k]));
             w.rsC[(bounce + 1) & 1][cost[k]][npos[k]] = make_float4(fLs[k].x, fLs[k].y, fLs[k].z, __int_as_float(seeds[k]));
-            if (w.sort_keys && cost[k] == 0) {
-                const unsigned oct = (rD[k].x < 0.0f ? 1u : 0u) | (rD[k].y < 0.0f ? 2u : 0u) | (rD[k].z < 0.0f ? 4u : 0u);
-                w.sort_keys[npos[k]] = (oct << w.key_shift) | (unsigned)tis[k];
-            }
         }
-}
-
-// in front of the sort: stream positions 0 .. cap-1 as the values, and the keys of the positions past the stream's end (left over
-// from an earlier bounce) pushed behind every live ray
-__global__ void wf_sort_prepare(WfParams w, int bounce, uint32_t* idx) {
-    const unsigned n = w.counters[wf_row(bounce) * kWfCounterStride + 0];
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (unsigned)w.npix) {
-        idx[i] = i;
-        if (i >= n) w.sort_keys[i] = ~0u;
-    }
-}
-
-size_t wf_sort_temp_bytes(int n, int end_bit) {
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, end_bit, (hipStream_t)0);
-    return bytes;
-}
-
-hipError_t launch_wf_sort(const WfParams& w, int bounce, uint32_t* idx, uint32_t* keys_alt, uint32_t* perm_out, void* temp, size_t temp_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_sort_prepare, dim3((w.npix + 255) / 256), dim3(256), 0, stream, w, bounce, idx);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)w.sort_keys, keys_alt, (const uint32_t*)idx, perm_out, w.npix, 0, std::min(32, w.key_shift + 3), stream);
 }
 
 hipError_t launch_wf_generate(const WfParams& w, hipStream_t stream) {

@@ -1292,34 +1292,3 @@ def test_wavefront_chains_render_the_same_frame(api, cb_spec):
             assert same_bits(sc.read_colors(), want_c) and np.array_equal(sc.read_rnds(), want_r), (spec.name, chains)
             sc.close()
         ref.close()
-
-
-def test_wavefront_ray_reorder_renders_the_same_frame(api, cb_spec):
-    """Option wf_sort: from bounce 1 on wf_intersect takes the class-0 rays of a bounce in sorted order (direction octant, then the
-    triangle the ray starts on) through a permutation of the stream positions.  Which wave traces a ray changes, what it finds
-    does not: same bits as the megakernel, one chain and four, cost classes on (Cornell box: class 1 stays in stream order) and
-    off (mesh)."""
-    from opencl_path_tracer_amd import scenes
-    W, H = 704, 400
-    for spec, pre, bounces in ((cb_spec, {}, 6), (scenes.displaced_grid_mesh(6000), {"wide_nodes": 2, "wide_lds_entries": 6}, 5)):
-        ref = api.Scene(W, H)
-        for k, v in pre.items():
-            ref.set_option(k, v)
-        ref.load(spec)
-        ref.iterations = bounces
-        ref.render(3)
-        want_c, want_r = ref.read_colors(), ref.read_rnds()
-        for chains in (1, 4):
-            sc = api.Scene(W, H)
-            for k, v in pre.items():
-                sc.set_option(k, v)
-            sc.load(spec)
-            sc.iterations = bounces
-            sc.set_option("variant", 1)
-            sc.set_option("wf_streams", chains)
-            sc.set_option("wf_sort", 1)
-            sc.render(2)
-            sc.render(1)
-            assert same_bits(sc.read_colors(), want_c) and np.array_equal(sc.read_rnds(), want_r), (spec.name, chains)
-            sc.close()
-        ref.close()

@@ -12,7 +12,6 @@ from opencl_path_tracer_amd import api, scenes  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("scenes")
 ap.add_argument("--ws", default="1,2,4,8")
-ap.add_argument("--sort", default="0", help="wf_sort values (ray reorder)")
 ap.add_argument("--reps", type=int, default=3)
 args = ap.parse_args()
 CASES = {"cornell": (scenes.cornell_box, 8, 8), "mesh100k": (lambda: scenes.displaced_grid_mesh(100000), 8, 4),
@@ -22,9 +21,8 @@ for name in args.scenes.split(","):
     sc = api.Scene(1920, 1080).load(make())
     sc.iterations = bounces
     sc.set_option("variant", 1)
-    for ws, srt in [(int(x), int(y)) for x in args.ws.split(",") for y in args.sort.split(",")]:
+    for ws in [int(x) for x in args.ws.split(",")]:
         sc.set_option("wf_streams", ws)
-        sc.set_option("wf_sort", srt)
         sc.render(spp)
         sc.sync()
         t = time.time()
@@ -33,6 +31,6 @@ for name in args.scenes.split(","):
         enq = time.time() - t           # the host's share: every launch of the passes enqueued
         sc.sync()
         dt = time.time() - t
-        print("%-9s wf_streams %d wf_sort %d (GPU_MAX_HW_QUEUES=%s): %8.1f Msamples/s   (enqueue %.2f ms of %.2f ms per sample pass)"
-              % (name, ws, srt, os.environ.get("GPU_MAX_HW_QUEUES", "default"), 1920 * 1080 * spp * args.reps / dt / 1e6, enq * 1e3 / (spp * args.reps), dt * 1e3 / (spp * args.reps)), flush=True)
+        print("%-9s wf_streams %d (GPU_MAX_HW_QUEUES=%s): %8.1f Msamples/s   (enqueue %.2f ms of %.2f ms per sample pass)"
+              % (name, ws, os.environ.get("GPU_MAX_HW_QUEUES", "default"), 1920 * 1080 * spp * args.reps / dt / 1e6, enq * 1e3 / (spp * args.reps), dt * 1e3 / (spp * args.reps)), flush=True)
     sc.close()
