@@ -125,6 +125,7 @@ struct pt_context {
     int flat_list = 16;        // at most this many big triangles go to the flat list (option flat_list; 0: none)
     int schedule = -1;     // megakernel: 0 lockstep per sample, 1 restart + tail suspension, -1 by the number of tiles per resident wave
     int suspend_lanes = -1; // tail suspension threshold of schedule 1 (-1: 24)
+    int migrate_lanes = -1;                         // option migrate_lanes (kSchedMigrate; -1: 1)
     int node_min_lanes = -1, leaf_min_lanes = -1;   // phase switching of the while-while rounds (-1: by node path, fill_params)
     int lbvh_ploc = 16;     // device-built trees: PLOC search radius (8 / 16 / 32); 0: Karras' radix tree over the Morton codes
     int lbvh_cluster = 64;  // device-built trees: the top above clusters of this many triangles is rebuilt with the host SAH (0: not)

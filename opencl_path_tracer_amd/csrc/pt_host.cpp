@@ -512,7 +512,7 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         if (value < 0 || value > 1000) return fail(ctx, PT_EINVAL, "sah_visit_cost: tenths of a triangle test, 0..1000");
         ctx->sah_visit_cost = (int)value;
     } else if (k == "schedule") {
-        if (value < -1 || value > 1) return fail(ctx, PT_EINVAL, "schedule: -1 automatic, 0 lockstep per sample, 1 restart + tail suspension");
+        if (value < -1 || value > 2) return fail(ctx, PT_EINVAL, "schedule: -1 automatic, 0 lockstep per sample, 1 restart + tail suspension, 2 the same with lanes moving on to the wave's next work item");
         ctx->schedule = (int)value;
     } else if (k == "flat_list") {
         if (value < 0 || value > 32) return fail(ctx, PT_EINVAL, "flat_list: 0..32 big triangles tested before the tree (a 32-bit candidate mask per lane)");
@@ -530,6 +530,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
     } else if (k == "node_min_lanes" || k == "leaf_min_lanes") {
         if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, k + ": -1 default, 0..63");
         (k == "node_min_lanes" ? ctx->node_min_lanes : ctx->leaf_min_lanes) = (int)value;
+    } else if (k == "migrate_lanes") {
+        if (value != -1 && (value < 1 || value > 64)) return fail(ctx, PT_EINVAL, "migrate_lanes: -1 default, 1..64");
+        ctx->migrate_lanes = (int)value;
     } else if (k == "suspend_lanes") {
         if (value < -1 || value > 63) return fail(ctx, PT_EINVAL, "suspend_lanes: -1 default, 0..63");
         ctx->suspend_lanes = (int)value;

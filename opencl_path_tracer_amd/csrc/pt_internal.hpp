@@ -139,6 +139,7 @@ struct RenderParams {
     int32_t suspend_lanes;       // megakernel: leave the traversal when at most this many lanes are unfinished (0: never)
     int32_t node_min_lanes;      // Trav::round: the node phase ends early when at most this many lanes still descend and another holds a leaf (0: never)
     int32_t leaf_min_lanes;      // ... and the leaf phase when at most this many lanes still hold leaves and another has a node (0: never)
+    int32_t migrate_lanes;       // kSchedMigrate: lanes that are done with the wave's current work item move to the next one when this many have gathered
     uint32_t* tile_cost;         // counting instances only, or null: [n_tiles] += shader-clock cycles / 64 the wave spent on each work item of the tile (pt_debug_tile_cost)
 };
 

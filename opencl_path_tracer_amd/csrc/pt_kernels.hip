@@ -64,7 +64,14 @@ __global__ void __launch_bounds__(256) k_gen_ray(RenderParams p) {
 //                  resume in the next trip, where their remaining visits overlap with everybody's new rays.
 //                  Costs more shading executions (each for fewer lanes): a loss when VALU-bound, +13-14 % on
 //                  the latency-bound mesh scenes where every wave-level step saved is a memory round trip saved.
-enum : int { kSchedLockstep = 0, kSchedSuspend = 1 };
+//
+//  kSchedMigrate   kSchedSuspend without the END of a work item.  A wave's item ends on its slowest pixel: the lanes' samples
+//                  are paths of 1 .. iterations segments, so after 32 samples the busiest lane of 64 has ~12 % more segments
+//                  behind it than the average one, and the last of them run for a handful of lanes (at 3-4 times the cost per
+//                  instruction, tools/micro/exec_ops.hip).  Here a lane whose pixel has had its samples writes it out and MOVES ON
+//                  to its pixel of the wave's next work item, which the wave fetches as soon as the first lane asks for it, while
+//                  the others finish: a wave has up to two items in hand, and only the end of the launch is a tail.  (render_items_migrating)
+enum : int { kSchedLockstep = 0, kSchedSuspend = 1, kSchedMigrate = 2 };
 
 
 // LEAN (the instances for 6 / 7 waves per SIMD: 80 / 72 VGPRs hold the traversal and little else): nothing that can be
@@ -220,6 +227,244 @@ PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, con
     }
 }
 
+// kSchedMigrate: the whole item loop of a persistent launch (p.tile_counter != 0), chained passes or whole tiles.
+//
+// Wave-uniform: the current item (cur_*) and, once a lane has finished its pixel of it, the next one (nxt_*), fetched from the work
+// counter like every item.  Per lane: the pixel in hand (li, pxy, seed, running mean), whether it belongs to the next item (on_next),
+// and `parked` = no pixel in hand (finished the item's pixel, or the tile has no pixel for this lane).
+//   * a lane whose pixel is done parks; parked lanes of the CURRENT item are moved to the next item as soon as that item may start;
+//   * a chained item may start when its tile's previous pass has been released.  While lanes still work on the current item that is
+//     only LOOKED AT (one relaxed load per trip) -- the wave never spins with unfinished work in hand, so the argument of k_render
+//     holds as it stands: a wave blocks only with every earlier item of its own released, on an item that was dequeued before;
+//   * when no lane works on the current item any more it is released, and the next item becomes the current one (lanes that have
+//     finished THAT one already stay parked until the item after it is fetched).
+// Results are those of the other schedules bit for bit: what a pixel computes never depends on which lanes run next to it.
+template <int MODE, bool COUNT, bool LEAN, bool SK>
+PT_DEV void render_items_migrating(const RenderParams& p, const SceneView& sv, const LaneStack<typename StackOf<MODE>::type> stk, WorkCount* wc,
+                                   unsigned long long* segs_tot, unsigned long long* samples_tot, unsigned long long* lane_steps) {
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    const bool chained = p.chunk_spp > 0;
+    const int n_pass = chained ? (p.nsamples + p.chunk_spp - 1) / p.chunk_spp : 1;
+    const int s_last = p.first_sample + p.nsamples;
+    const int camX = (int)p.cam.XM;
+    // ---- per lane
+    f3 rP = mk(0.f, 0.f, 0.f), rD = mk(0.f, 0.f, 1.f);
+    PathRegs st;
+    st.reset();
+    bool inside = false;
+    int seed = 0;
+    f3 acc = mk(0.0f, 0.0f, 0.0f);
+    int s = 0, bounce = 0;
+    bool fresh = true, traversing = false;
+    bool parked = true, on_next = false;
+    int li = 0;
+    unsigned pxy = 0;
+    unsigned my_segs = 0;
+    Trav<MODE> tr;
+    tr.setup(rP, rD);
+    tr.restart(stk);
+    tr.idle();
+    // ---- per wave (scalar registers: readfirstlane at every redefinition, as in k_render).  An item is the number the work
+    // counter gave (pass * n_tiles + tile; -1: none): two registers for the two items in hand, everything else is derived
+    int cur_item = -1, nxt_item = -1;
+    int cur_end = 0, nxt_end = 0;          // where their samples end
+    int nxt_ready = 0, no_more = 0;
+    unsigned long long samples = 0;
+    auto pass_of = [&](int item) { return chained ? item / p.n_tiles : 0; };
+    auto tile_of = [&](int item) { return chained ? item - (item / p.n_tiles) * p.n_tiles : item; };
+
+    // the next work item off the counter; -1: none left (every wave gets exactly one such answer: k_render's exit protocol)
+    auto fetch = [&]() {
+        int t = 0;
+        if (lane0) t = (int)atomicAdd(p.tile_counter, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const bool ok = chained ? t / p.n_tiles < n_pass : t < p.n_tiles;
+        return __builtin_amdgcn_readfirstlane(ok ? t : -1);
+    };
+    auto released = [&](int item) {        // has the tile's previous pass been handed over?  (one look)
+        const int pass = pass_of(item);
+        if (pass == 0) return 1;
+        unsigned seen = 0;
+        if (lane0) seen = __hip_atomic_load(&p.tile_done[tile_of(item)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+        return __builtin_amdgcn_readfirstlane((int)(seen >= (unsigned)pass));
+    };
+    // the bounded wait of k_render: 1 when the hand-over came, 0 when it was lost (here or elsewhere)
+    auto wait_released = [&](int item) {
+        const int pass = pass_of(item), tile = tile_of(item);
+        if (pass == 0) return 1;
+        unsigned seen = 0, lost = 0, polls = 0;
+        const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            if (lane0) seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+            if (seen >= (unsigned)pass) break;
+            if ((++polls & 63u) == 0) {
+                if (lane0) lost = __hip_atomic_load(&p.tile_counter[kTileCounterError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lost = (unsigned)__builtin_amdgcn_readfirstlane((int)lost);
+                if (lost != 0) break;
+                if (__builtin_amdgcn_s_memrealtime() - w0 > (unsigned long long)p.poll_ticks) {
+                    const unsigned long long mine = ((unsigned long long)(unsigned)pass << 32) | (unsigned long long)((unsigned)tile + 1u);
+                    unsigned long long was = 0;
+                    if (lane0) was = atomicCAS(reinterpret_cast<unsigned long long*>(&p.tile_counter[kTileCounterError]), 0ull, mine);
+                    const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)was);
+                    lost = first != 0 ? first : (unsigned)tile + 1u;
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        return __builtin_amdgcn_readfirstlane((int)(seen >= (unsigned)pass));
+    };
+    auto end_of = [&](int item) { return chained ? min(p.first_sample + (pass_of(item) + 1) * p.chunk_spp, s_last) : s_last; };
+    // this lane's pixel of an item: LCG state, running mean, first sample
+    // this lane's pixel of an item: LCG state, running mean, first sample.  A lane comes here on its own, a few at a time, so
+    // what pixel_of_wave() and prog.cl:84-85 spend on integer divisions per lane is done on the scalar unit where the frame
+    // allows it (tile rows never straddle a block of rows_per_block rows when that is a multiple of 8; camera as wide as the frame)
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (p.width + 7) >> 3;
+    const bool rows_aligned = (p.rows_per_block & 7) == 0;
+    auto take_pixel = [&](int item) {
+        const int tile = tile_of(item);
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;            // (wave-uniform: scalar unit)
+        const int x = tx * 8 + (lane & 7), lrow = ty * 8 + (lane >> 3);
+        if (x >= p.width || lrow >= p.local_rows) return;                   // (stays parked: the tile has no pixel for this lane)
+        int grow;
+        if (p.world == 1) grow = lrow;
+        else if (rows_aligned) { const int r0 = ty * 8; grow = ((r0 / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (r0 % p.rows_per_block) + (lane >> 3); }
+        else grow = ((lrow / p.rows_per_block) * p.world + p.rank) * p.rows_per_block + (lrow % p.rows_per_block);
+        li = lrow * p.width + x;
+        int gx = x, gy = grow;                                               // prog.cl:84-85: id % X, id / X with id = grow * width + x
+        if (camX != p.width) { const int gid = grow * p.width + x; gx = gid % camX; gy = gid / camX; }
+        pxy = (unsigned)gx | ((unsigned)gy << 16);
+        seed = p.rnds[li];
+        s = p.first_sample + pass_of(item) * p.chunk_spp;
+        if (!LEAN) {
+            acc = mk(0.0f, 0.0f, 0.0f);
+            if (s != 0) {                          // prog.cl:312-314: sample 0 starts from black
+                const float4 c = p.colors[li];
+                acc = mk(c.x, c.y, c.z);
+            }
+        }
+        fresh = true;
+        traversing = false;
+        bounce = 0;
+        parked = false;
+    };
+
+    for (;;) {
+        if (COUNT && first_active_lane()) wc->wtrips++;
+        // ---- a pixel that has had its samples of the item is written out
+        if (!parked && fresh && !traversing && s == (on_next ? nxt_end : cur_end)) {
+            if (!LEAN) p.colors[li] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+            p.rnds[li] = seed;
+            parked = true;
+        }
+        // ---- the wave's items
+        if (__ballot(!parked && !on_next) == 0) {
+            // nobody works on the current item any more: hand it over, the next one becomes the current one
+            if (cur_item >= 0 && chained) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // keep the wait the compiler may drop (guide, G16)
+                const int tile = tile_of(cur_item), pass = pass_of(cur_item);
+                if (lane0 && !(tile == p.debug_stall_tile && pass == 0)) {
+                    unsigned handed;             // (the number comes out of a scalar register right here: tools/check_isa.py, rule 2)
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(handed) : "s"(__builtin_amdgcn_readfirstlane(pass + 1)));
+                    __hip_atomic_store(&p.tile_done[tile], handed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            cur_item = -1;
+            if (nxt_item < 0 && !no_more) {
+                nxt_item = fetch();
+                no_more = __builtin_amdgcn_readfirstlane((int)(nxt_item < 0));
+                nxt_ready = 0;
+            }
+            if (nxt_item < 0) break;                                 // no item left, nothing in hand
+            if (!nxt_ready) {
+                if (!wait_released(nxt_item)) break;                 // a hand-over was lost somewhere: this wave renders nothing more
+                if (pass_of(nxt_item) > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            cur_item = __builtin_amdgcn_readfirstlane(nxt_item);
+            cur_end = __builtin_amdgcn_readfirstlane(end_of(nxt_item));
+            nxt_item = -1;
+            nxt_ready = 0;
+            if (on_next) on_next = false;                            // already at work on it (or done with it: stays parked)
+            else take_pixel(cur_item);                               // (every lane that was not on it is parked here)
+        } else if (__popcll(__ballot(parked && !on_next)) >= p.migrate_lanes) {
+            // lanes are done with the current item while others still work on it: start them on the next one, if it may start
+            // (migrate_lanes = how many must have gathered: moving one by one measured best, profiles/r04/r_*)
+            if (nxt_item < 0 && !no_more) {
+                nxt_item = fetch();
+                no_more = __builtin_amdgcn_readfirstlane((int)(nxt_item < 0));
+                nxt_ready = 0;
+                nxt_end = __builtin_amdgcn_readfirstlane(end_of(nxt_item));
+            }
+            if (nxt_item >= 0 && !nxt_ready && released(nxt_item)) {
+                if (pass_of(nxt_item) > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                nxt_ready = 1;
+            }
+            if (nxt_item >= 0 && nxt_ready && parked && !on_next) {
+                on_next = true;
+                take_pixel(nxt_item);
+            }
+        }
+        // ---- the segment loop of kSchedSuspend for the lanes with a pixel in hand
+        if (!parked && fresh && !traversing) {       // a lane whose path ended starts its next sample right here
+            st.reset();                              // prog.cl:307-316
+            inside = false;
+            const float rnd1 = lcg_rand(seed), rnd2 = lcg_rand(seed);
+            camera_get_ray_xy((float)(pxy & 0xffffu), (float)(pxy >> 16), p.cam, rnd1, rnd2, &rP, &rD);
+            bounce = 0;
+            fresh = false;
+        }
+        bool finished = !parked;
+        if (!parked && (traversing || bounce < p.iterations)) {
+            tr.setup(rP, rD);                        // direction-dependent constants: recomputed for new and resumed rays alike
+            if (!traversing) {
+                tr.restart(stk);
+                tr.template flat_pass<COUNT>(sv, wc);
+            }
+            for (;;) {
+                if (COUNT && first_active_lane()) wc->wrounds++;
+                tr.template round<COUNT>(sv, wc);
+                const unsigned long long unfinished = __ballot(!tr.done());
+                if (unfinished == 0) break;
+                if (__popcll(unfinished) <= p.suspend_lanes && __ballot(tr.done()) != 0) break;
+            }
+            traversing = !tr.done();
+            if (traversing) {
+                finished = false;
+            } else {
+                ++my_segs;
+                if (tr.best >= 0) {
+                    if (COUNT) { if (first_active_lane()) wc->wshade++; count_low(wc, 3); }
+                    shade_hit<SK>(rP, rD, st, seed, inside, p, sv.tris, sv.meta, tr.best, tr.best_t);
+                    ++bounce;
+                    finished = (bounce >= p.iterations);
+                }
+            }
+        }
+        samples += (unsigned long long)__popcll(__ballot(finished));
+        if (finished) {
+            if (LEAN) fold_sample(p, li, st.C(), s);
+            else acc = running_mean(acc, st.C(), s);
+            ++s;
+            fresh = true;
+        }
+    }
+    {
+        unsigned v = my_segs;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        *segs_tot += (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+        *samples_tot += samples;
+    }
+    if (COUNT) {      // segment-steps of the wave = 64 x its busiest lane's segments (over all its items: lanes move on their own)
+        unsigned mx = my_segs;
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_down(mx, off, 64));
+        *lane_steps += (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)mx) * 64ull;
+    }
+}
+
 // The render kernel.  One wave = one 8x8 pixel tile; each lane owns one pixel.
 //
 // Launch modes:
@@ -262,6 +507,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
     unsigned long long segs_tot = 0, samples_tot = 0, item_lane_steps = 0;
     int tile = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     int pass = 0;
+    if (SCHED == kSchedMigrate) {                                // (persistent launches only: launch_render_mega)
+        if (p.tile_counter) render_items_migrating<MODE, COUNT, kLean, kScalarK>(p, sv, stk, &wc, &segs_tot, &samples_tot, &item_lane_steps);
+    } else
     for (;;) {
         if (p.tile_counter) {                                    // ---- fetch the next work item
             // (the work item is wave-uniform: kept in scalar registers -- readfirstlane, not a lane shuffle -- so that
@@ -511,6 +759,8 @@ hipError_t launch_trace_ray(const RenderParams& p, const LaunchConfig& lc, hipSt
 hipError_t launch_render_mega(const RenderParams& p, const LaunchConfig& lc, hipStream_t stream) {
     if (lc.schedule == kSchedLockstep)
         return lc.count_work ? launch_render_t<false, true, kSchedLockstep>(p, lc, stream) : launch_render_t<false, false, kSchedLockstep>(p, lc, stream);
+    if (lc.schedule == kSchedMigrate && p.tile_counter)
+        return lc.count_work ? launch_render_t<false, true, kSchedMigrate>(p, lc, stream) : launch_render_t<false, false, kSchedMigrate>(p, lc, stream);
     return lc.count_work ? launch_render_t<false, true, kSchedSuspend>(p, lc, stream) : launch_render_t<false, false, kSchedSuspend>(p, lc, stream);
 }
 

@@ -182,6 +182,7 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     // Msamples/s; 4-wide nodes from global memory 0/0 839 | 294, 4/4 1012 | 367, 6/4 1028 | 373, 8/8 1031 | 371 (MESH-100k | MESH-1M)
     p->node_min_lanes = ctx->node_min_lanes >= 0 ? ctx->node_min_lanes : (p->node_mode == kNodesLds ? 3 : 6);
     p->leaf_min_lanes = ctx->leaf_min_lanes >= 0 ? ctx->leaf_min_lanes : 4;
+    p->migrate_lanes = ctx->migrate_lanes > 0 ? ctx->migrate_lanes : 1;      // (1 / 9 / 20: MESH-100k 1,192 / 1,112 / 1,113 -- waiting for company costs more than moving alone)
 }
 
 int check_ready(pt_context* ctx, const pt_camera* cam) {
@@ -271,7 +272,8 @@ static int ptamd_resident_waves(const pt_context*, const LaunchConfig& lc) { ret
 // Samples per (pass, tile) work item of a persistent launch, by tiles per resident wave (0: whole tiles).
 // fewer tiles per resident wave (1080p over 2 / 4 / 8 GPUs: 4.0 / 2.0 / 1.0): suspend with passes of 16, lockstep with
 // passes of 8, lockstep with whole tiles (profiles/r02/q_*: 95.7 % / 87.5 % / 61.8 % of the one-GPU rate per GPU)
-static int auto_chunk_spp(int n_tiles, int resident_waves, int nsamples) {
+static int auto_chunk_spp(int n_tiles, int resident_waves, int nsamples, int schedule) {
+    if (schedule == 2) return nsamples >= 32 ? 8 : nsamples >= 8 ? 4 : 0;
     return n_tiles >= 5 * resident_waves ? (nsamples >= 256 ? 64 : 32)
          : n_tiles >= 3 * resident_waves ? 16
          : n_tiles > resident_waves + resident_waves / 4 ? 8 : 0;
@@ -308,7 +310,12 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
     // ahead give up the coherence of a tile's camera rays -- lockstep up to 4 samples per launch with the tree in LDS
     // (render(1): 1,810 against 1,492 Msamples/s), for one sample otherwise (profiles/r03/q_*)
     const bool few_samples = p.nsamples <= (p.node_mode == kNodesLds ? 4 : 1);
-    lc->schedule = ctx->schedule >= 0 ? ctx->schedule : (!few_samples && p.n_tiles >= 3 * ptamd_resident_waves(ctx, *lc) ? 1 : 0);
+    // Round 4: where the restart schedule is taken AND the nodes come from global memory, its lanes also move on to the wave's next
+    // work item instead of waiting for the item's slowest pixel (schedule 2, render_items_migrating): MESH-100k 1,099 -> 1,190,
+    // MESH-1M 423 -> 456 Msamples/s at 64 samples per launch.  With the tree in LDS the same costs 1 % (2,646 -> 2,624: the VALU-bound
+    // instance pays for five more spilled dwords what it gains in lanes), so the Cornell box keeps schedule 1 (profiles/r04/r_*).
+    const int restart = (ctx->persistent && p.node_mode != kNodesLds) ? 2 : 1;
+    lc->schedule = ctx->schedule >= 0 ? ctx->schedule : (!few_samples && p.n_tiles >= 3 * ptamd_resident_waves(ctx, *lc) ? restart : 0);
     ctx->last_lds_bytes = lc->lds_bytes;
     ctx->last_waves_per_simd = lc->waves_per_simd;
 }
@@ -475,7 +482,9 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         // 8 / 16 / 32 / 64 -> 1689 / 1760 / 1787 / 1761 Msamples/s; 256 spp: 1706 / 1789 / 1843 / 1868
         // (profiles/r02/n_*; the lockstep kernel of round 1 peaked at 8).
         const int resident_waves = ptamd_resident_waves(ctx, lc);
-        const int auto_chunk = auto_chunk_spp(p.n_tiles, resident_waves, nsamples);
+        // (schedule 2 has no tail at the end of an item to amortise: short passes, which re-balance the chip -- 4 / 8 / 16 / 32 samples per
+        // item at 64 per launch: MESH-100k 1,138 / 1,190 / 1,186 / 1,146, MESH-1M 443 / 456 / 456 / 442; at 16 per launch 4 and 8 lead)
+        const int auto_chunk = auto_chunk_spp(p.n_tiles, resident_waves, nsamples, lc.schedule);
         const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk;
         // work items are numbered with an int on the device: passes x tiles + one failed fetch per resident wave
         const int64_t items = chunk > 0 ? ((int64_t)nsamples + chunk - 1) / chunk * p.n_tiles : p.n_tiles;
@@ -546,7 +555,7 @@ int pt_debug_launch_plan(pt_context* ctx, int32_t nsamples, int32_t cu_count, in
     ctx->cu_count = saved_cu;
     ctx->last_lds_bytes = saved_lds;
     ctx->last_waves_per_simd = saved_wps;
-    const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk_spp(p.n_tiles, resident, nsamples);
+    const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk_spp(p.n_tiles, resident, nsamples, lc.schedule);
     out[0] = lc.block; out[1] = lc.waves_per_simd; out[2] = lc.schedule; out[3] = (chunk > 0 && nsamples > chunk) ? chunk : 0;
     out[4] = resident; out[5] = p.n_tiles; out[6] = p.node_mode; out[7] = (int64_t)lc.lds_bytes;
     return PT_OK;

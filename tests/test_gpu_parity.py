@@ -927,11 +927,11 @@ def test_image_files_of_a_render(api, cb_spec, tmp_path):
     assert raw[0] == b"P6" and np.array_equal(np.frombuffer(raw[3], dtype=np.uint8).reshape(H, W, 3), exp8)
 
 
-@pytest.mark.parametrize("schedule,k", [(0, -1), (1, 0), (1, 1), (1, 8), (1, 24), (1, 63)])
+@pytest.mark.parametrize("schedule,k", [(0, -1), (1, 0), (1, 1), (1, 8), (1, 24), (1, 63), (2, 1), (2, 24)])
 def test_schedules_identical(api, oracle, cb_spec, cb_oracle_scene, schedule, k):
-    """The megakernel's two schedules -- 0: lockstep per sample, 1: restart + tail suspension (the wave leaves
-    closest_hit when at most k lanes are still traversing; the stragglers resume in the next trip) -- only
-    change what a wave executes together: same frame, same LCG states, same segment count, on the
+    """The megakernel's schedules -- 0: lockstep per sample, 1: restart + tail suspension (the wave leaves
+    closest_hit when at most k lanes are still traversing; the stragglers resume in the next trip), 2: the same with
+    lanes moving on to the wave's next work item when their pixel is done -- only change what a wave executes together: same frame, same LCG states, same segment count, on the
     whole-tree-in-LDS path, the L1/L2 path and the treelet path, with chained passes, with and without the
     counting kernel instance."""
     from opencl_path_tracer_amd import scenes
@@ -1292,3 +1292,78 @@ def test_wavefront_chains_render_the_same_frame(api, cb_spec):
             assert same_bits(sc.read_colors(), want_c) and np.array_equal(sc.read_rnds(), want_r), (spec.name, chains)
             sc.close()
         ref.close()
+
+
+@pytest.mark.parametrize("W,H,chunk,spp,world,rb", [(80, 56, 2, 7, 1, 8), (16, 8, 1, 6, 1, 8), (203, 131, 3, 7, 1, 8), (96, 80, 0, 5, 1, 8),
+                                                    (64, 72, 2, 5, 3, 8), (64, 72, 2, 5, 2, 12), (64, 60, 1, 4, 4, 4)])
+def test_migrating_schedule(api, oracle, cb_spec, cb_oracle_scene, W, H, chunk, spp, world, rb):
+    """Schedule 2 (render_items_migrating): a lane whose pixel has had its samples of the wave's work item writes it out and starts
+    on its pixel of the wave's NEXT item while the others finish -- a wave has two items in hand, a chained item is only looked at,
+    never waited for, while work is left on the current one.  Compared with the oracle in every pixel: chained passes (down to one
+    sample per item; frames of two tiles, where a wave's next item is the next pass of the tile it is still working on; ragged frames),
+    whole tiles, the tiles of a rank of 2 / 3 / 4 (rows_per_block a multiple of 8 or not: the two ways a lane finds its pixel), with
+    one lane moving at a time and with sixteen, for the tree in LDS and for 4-wide nodes from global memory."""
+    from opencl_path_tracer_amd import scenes
+    fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 5, spp)
+    ocols, ornds = fr.colors(), fr.rnds()
+    for r in range(world):
+        for lds, ml in ((2, 1), (0, 16)):
+            sc = api.Scene(W, H, rank=r, world=world, rows_per_block=rb)
+            sc.set_option("lds_scene", lds)
+            sc.load(cb_spec)
+            sc.set_option("schedule", 2)
+            sc.set_option("chunk_spp", chunk)
+            sc.set_option("migrate_lanes", ml)
+            sc.iterations = 5
+            sc.render(spp - 2)
+            sc.render(2)
+            ids = sc.local_pixel_ids()
+            assert same_bits(sc.read_colors()[:, :3], ocols[ids, :3]) and np.array_equal(sc.read_rnds(), ornds[ids]), (r, lds, ml)
+            if world == 1:
+                assert sc.stat("segments") == segs and sc.stat("samples") == W * H * spp
+            sc.close()
+    if world == 1 and chunk == 2:
+        spec = scenes.displaced_grid_mesh(6000)
+        osc = oracle.load_scene(spec)
+        fr2, segs2 = oracle_render(oracle, osc, spec, 64, 64, 6, 6)
+        sc = api.Scene(64, 64)
+        sc.set_option("wide_nodes", 2)
+        sc.set_option("wide_lds_entries", 6)
+        sc.load(spec)
+        sc.set_option("schedule", 2)
+        sc.set_option("chunk_spp", chunk)
+        sc.iterations = 6
+        sc.render(6)
+        check(sc, fr2, "schedule 2, 4-wide nodes")
+        assert sc.stat("segments") == segs2
+        sc.close()
+
+
+def test_lost_hand_over_under_the_migrating_schedule(api, cb_spec):
+    """The bounded hand-over poll of the chained passes holds for schedule 2 as well: a wave blocks only when nothing is left of
+    its current item, and then with the same time limit -- a release that never comes (debug_stall_tile) ends in PT_EHIP, and the
+    context renders the right frame afterwards."""
+    import time
+    W = H = 256
+    ref = api.Scene(W, H).load(cb_spec)
+    ref.iterations = 4
+    ref.render(8)
+    want_c, want_r = ref.read_colors(), ref.read_rnds()
+    sc = api.Scene(W, H).load(cb_spec)
+    sc.iterations = 4
+    sc.set_option("schedule", 2)
+    sc.set_option("chunk_spp", 2)
+    sc.set_option("poll_timeout_ms", 60)
+    sc.set_option("debug_stall_tile", 37)
+    t0 = time.time()
+    sc.render(8)
+    with pytest.raises(api.PtError) as e:
+        sc.sync()
+    assert e.value.code == api.PT_EHIP and "pass 1 of tile 37" in str(e.value), str(e.value)
+    assert time.time() - t0 < 20.0
+    sc.set_option("debug_stall_tile", -1)
+    sc.current_sample = 0
+    sc.seed_default()
+    sc.render(8)
+    sc.sync()
+    assert same_bits(sc.read_colors(), want_c) and np.array_equal(sc.read_rnds(), want_r)

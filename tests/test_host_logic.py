@@ -306,6 +306,13 @@ def test_launch_plan_of_a_rank_of_eight(api, cb_spec):
     assert (p4["block"], p4["waves_per_simd"], p4["schedule"], p4["chunk_spp"]) == (512, 4, 0, 8), p4
     k8 = plan(3840, 2160, 5, 8)             # 16,320 tiles: 2.7 per resident wave
     assert (k8["block"], k8["waves_per_simd"], k8["schedule"], k8["chunk_spp"]) == (768, 6, 0, 8), k8
+    # nodes from global memory (as for a mesh): the restart schedule is the one whose lanes move on to the next work item, in short passes
+    sc = api.Scene(1920, 1080, device=None)
+    sc.set_option("lds_scene", 0)
+    sc.load(cb_spec)
+    m64, m16, m4 = sc.debug_launch_plan(64, 256), sc.debug_launch_plan(16, 256), sc.debug_launch_plan(4, 256)
+    assert (m64["block"], m64["waves_per_simd"], m64["schedule"], m64["chunk_spp"]) == (256, 7, 2, 8) and m64["node_mode"] != 0, m64
+    assert (m16["schedule"], m16["chunk_spp"]) == (2, 4) and (m4["schedule"], m4["chunk_spp"]) == (2, 0), (m16, m4)
 
 
 def test_device_policies_fall_back_to_the_tree_they_name(api):
