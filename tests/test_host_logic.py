@@ -183,7 +183,7 @@ def test_scene_size_cap(api):
 def test_option_validation(api):
     sc = api.Scene(8, 8, device=None)
     for key, bad in (("variant", 2), ("lds_scene", 1), ("lds_scene", 3), ("treelet", -2), ("treelet", 5000), ("chunk_spp", -2),
-                     ("sah_visit_cost", -1), ("schedule", 2), ("schedule", -2), ("flat_list", -1), ("flat_list", 33), ("tile_order", 1), ("suspend_lanes", 64), ("suspend_lanes", -2), ("debug_repeat", -1), ("debug_repeat", 100000), ("bvh_policy", 6), ("bvh_device", 2), ("bvh_device", -2), ("sah_grain", 4), ("wide_on_device", 2),
+                     ("sah_visit_cost", -1), ("schedule", 3), ("schedule", -2), ("migrate_lanes", 0), ("migrate_lanes", 65), ("flat_list", -1), ("flat_list", 33), ("tile_order", 1), ("suspend_lanes", 64), ("suspend_lanes", -2), ("debug_repeat", -1), ("debug_repeat", 100000), ("bvh_policy", 6), ("bvh_device", 2), ("bvh_device", -2), ("sah_grain", 4), ("wide_on_device", 2),
                      ("block", 256), ("min_waves", 4), ("traversal", 1), ("pixel_map", 1), ("no_such_option", 0)):
         with pytest.raises(api.PtError) as e:
             sc.set_option(key, bad)
