@@ -1,6 +1,6 @@
 """Strong-scaling probe on ONE GPU, by kernel instance and schedule: times the tile sets of ranks 0, N/2, N-1 of an N-rank
 job (render only; the ranks of a real job run concurrently, so the job time is the slowest rank's) for the two LDS-tree
-instances of k_render (lds_block 512 = 4 waves per SIMD at 128 VGPRs, 768 = 6 waves at 80 VGPRs), both schedules and
+instances of k_render (lds_block 512 = 4 waves per SIMD at 128 VGPRs, 768 = 6 waves at 80 VGPRs), the three schedules and
 several pass lengths.  Prints the projected whole-job rate and the efficiency against the best N = 1 time.
   python tools/scaling_probe2.py [W H] [full]"""
 import sys
@@ -34,7 +34,7 @@ best1 = None
 for world in (1, 2, 4, 8):
     cases = [dict(lds_block=b) for b in (512, 768)]
     if world > 1 or "full" in sys.argv:
-        cases += [dict(lds_block=b, schedule=s, chunk_spp=c) for b in (512, 768) for s, c in ((0, 0), (0, 8), (1, 16), (1, 32))]
+        cases += [dict(lds_block=b, schedule=s, chunk_spp=c) for b in (512, 768) for s, c in ((0, 0), (0, 8), (1, 16), (1, 32), (2, 2), (2, 4), (2, 8), (2, 16))]
     for opts in cases:
         ts = [t_rank(world, r, **opts) for r in sorted(set([0, world // 2, world - 1]))]
         worst = max(ts)
