@@ -193,9 +193,12 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *                  1,024-thread workgroup's stacks (~750-1,000), 2..2048; set before the triangles are uploaded
  *   "schedule"     megakernel: 1 a lane whose path ended starts its next sample at once and the wave leaves a traversal
  *                  when at most "suspend_lanes" lanes are unfinished (they resume in the next trip); 0 lockstep: all
- *                  lanes of a wave start a sample together; -1 (default) 1 when the context has >= 3 tiles per
- *                  resident wave (one or two GPUs at 1080p), else 0
- *   "suspend_lanes" -1 (default: 24), 0..63
+ *                  lanes of a wave start a sample together; 2 like 1, and a lane whose pixel has had its samples of the
+ *                  wave's work item moves on to its pixel of the wave's next item instead of waiting for the item's
+ *                  slowest pixel (persistent launches; "migrate_lanes": how many such lanes must have gathered, default 1);
+ *                  -1 (default) by tiles per resident wave: from 3 (one or two GPUs at 1080p) 1 for a tree in LDS and
+ *                  2 for nodes from global memory, else 0
+ *   "suspend_lanes" -1 (default: 16 for a tree in LDS, else 24), 0..63
  *   "lbvh_cluster" device-built trees (bvh_policy 4): the top of the tree above clusters of at most this many triangles is
  *                  rebuilt with the host's SAH over the cluster boxes (default 64; 0: the LBVH as the device built it);
  *                  set before the triangles are uploaded
@@ -249,10 +252,11 @@ int pt_debug_scene_sizes(const pt_context* ctx, int64_t* ntris, int64_t* nmats, 
 int pt_debug_scene_copy(const pt_context* ctx, pt_triangle* tris, pt_material* mats, int32_t* obj_begin);
 /* the reference's traversal encounter rank of each triangle, in add order */
 int pt_debug_encounter_rank(const pt_context* ctx, int32_t* out, int64_t n);
-/* after a counting launch (option count_work = 1, pt_render): per 8x8 tile of the local frame, shader-clock cycles / 64 spent on it */
+/* after a counting launch (option count_work = 1, pt_render; schedules 0 and 1 -- under schedule 2 a wave works on two tiles at
+ * once and leaves this zero): per 8x8 tile of the local frame, shader-clock cycles / 64 spent on it */
 int pt_debug_tile_cost(pt_context* ctx, uint32_t* out, int64_t n_tiles);
 /* What pt_render(nsamples) would launch on a device of cu_count compute units (0: the context's own; works on a host-only
- * context): out[8] = { threads per workgroup, waves per SIMD, schedule (0 lockstep, 1 suspend), samples per (pass, tile)
+ * context): out[8] = { threads per workgroup, waves per SIMD, schedule (0 lockstep, 1 suspend, 2 migrate), samples per (pass, tile)
  * work item (0: whole tiles), resident waves, tiles, node mode, dynamic LDS bytes }.  Lets CPU tests pin the launch policy
  * of a rank of an N-GPU job. */
 int pt_debug_launch_plan(pt_context* ctx, int32_t nsamples, int32_t cu_count, int64_t out[8]);
