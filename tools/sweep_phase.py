@@ -1,6 +1,6 @@
 """Phase-switch thresholds of the while-while rounds (options node_min_lanes / leaf_min_lanes) and the suspension threshold
 (suspend_lanes) on the BASELINE scenes.
-usage: python tools/sweep_phase.py <scene,...> [--nm 0,4,8] [--lm 0] [--sl -1] [--reps 3]     scene: cornell mesh100k mesh1m wf wf100k"""
+usage: python tools/sweep_phase.py <scene[:spp],...> [--nm 0,4,8] [--lm 0] [--sl -1] [--reps 3]     scene: cornell mesh100k mesh1m wf wf100k"""
 import argparse
 import itertools
 import sys
@@ -20,8 +20,10 @@ CASES = {"cornell": (scenes.cornell_box, 8, 64, 0), "mesh100k": (lambda: scenes.
          "mesh1m": (lambda: scenes.displaced_grid_mesh(1000000), 16, 8, 0), "wf": (scenes.cornell_box, 8, 8, 1),
          "wf100k": (lambda: scenes.displaced_grid_mesh(100000), 8, 4, 1)}
 ints = lambda s: [int(x) for x in s.split(",")]
-for name in args.scenes.split(","):
+for item in args.scenes.split(","):
+    name, _, spp_s = item.partition(":")          # scene[:samples per launch]
     make, bounces, spp, variant = CASES[name]
+    spp = int(spp_s) if spp_s else spp
     sc = api.Scene(1920, 1080).load(make())
     sc.iterations = bounces
     sc.set_option("variant", variant)
