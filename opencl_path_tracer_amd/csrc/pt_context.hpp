@@ -119,6 +119,7 @@ struct pt_context {
     uint32_t* d_tile_counter = nullptr;
     uint32_t* d_tile_done = nullptr;
     uint32_t* d_tile_cost = nullptr;   // count_work: per tile, cycles / 64 its waves spent on it in the last launch (pt_debug_tile_cost)
+    int chunk_taper = -1;  // option chunk_taper: shortest pass of a launch whose last passes taper off (0: all passes chunk_spp long; -1 default)
     int chunk_spp = -1;   // persistent megakernel work items: > 0 (pass, tile) items of that many samples, 0 whole
                           // tiles, -1 automatic (4 when the context has clearly more tiles than resident waves)
     int sah_visit_cost = 10;   // tenths of a triangle test (option sah_visit_cost)

@@ -503,6 +503,9 @@ int pt_set_option(pt_context* ctx, const char* key, int64_t value) {
         ctx->timing = value ? 1 : 0;
     } else if (k == "count_work") {
         ctx->count_work = value ? 1 : 0;
+    } else if (k == "chunk_taper") {
+        if (value < -1 || value > 1 << 15) return fail(ctx, PT_EINVAL, "chunk_taper: -1 default, 0 off, else the shortest pass");
+        ctx->chunk_taper = (int)value;
     } else if (k == "chunk_spp") {
         if (value < -1 || value > 1 << 20) return fail(ctx, PT_EINVAL, "chunk_spp out of range");
         ctx->chunk_spp = (int)value;

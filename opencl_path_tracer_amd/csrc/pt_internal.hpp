@@ -73,6 +73,7 @@ constexpr int kMaxDepth = 30;      // builder guarantees depth <= kMaxDepth
 constexpr int kTileCounterError = 16;  // word of RenderParams::tile_counter that holds 1 + tile of a lost hand-over (word 17: the pass) -- on a cache
                                        // line of its own: the waves that poll for a hand-over look at it now and then, and the line of words 0 / 1
                                        // takes every work-item fetch of the launch
+constexpr int kMaxTaperPasses = 30;   // passes of a launch whose lengths are tabled (RenderParams::taper_end)
 constexpr int kTileCounterWords = 32;  // words of the work counter (two 64-byte lines)
 constexpr int kStatRows = 256;     // statistics counters are spread over this many rows of kStatCols
 constexpr int kStatCols = 16;
@@ -133,6 +134,10 @@ struct RenderParams {
                                  // reports the tile in word 4 and the launch winds down (pt_sync then returns PT_EHIP)
     int32_t debug_stall_tile;    // tests: pass 0 of this tile is rendered but never published (-1: none)
     int32_t n_tiles;
+    // passes of DIFFERENT lengths (option chunk_taper): n_taper > 0 -> pass k of a tile is samples [taper_end[k-1], taper_end[k]) of the
+    // launch (taper_end[-1] = 0), n_taper passes in all; the last passes are short, so that the launch does not end on whole long items
+    int32_t n_taper;
+    uint16_t taper_end[kMaxTaperPasses];
     int32_t chunk_spp;           // > 0: a work item is (pass, tile) = chunk_spp samples of a tile; passes of one
                                  // tile are chained through tile_done[] (agent-scope release / acquire)
     uint32_t* tile_done;         // [n_tiles] number of passes completed, zeroed before the launch

@@ -244,7 +244,7 @@ PT_DEV void render_items_migrating(const RenderParams& p, const SceneView& sv, c
                                    unsigned long long* segs_tot, unsigned long long* samples_tot, unsigned long long* lane_steps) {
     const bool lane0 = (threadIdx.x & 63) == 0;
     const bool chained = p.chunk_spp > 0;
-    const int n_pass = chained ? (p.nsamples + p.chunk_spp - 1) / p.chunk_spp : 1;
+    const int n_pass = chained ? (p.n_taper > 0 ? p.n_taper : (p.nsamples + p.chunk_spp - 1) / p.chunk_spp) : 1;
     const int s_last = p.first_sample + p.nsamples;
     const int camX = (int)p.cam.XM;
     // ---- per lane
@@ -316,7 +316,8 @@ PT_DEV void render_items_migrating(const RenderParams& p, const SceneView& sv, c
         }
         return __builtin_amdgcn_readfirstlane((int)(seen >= (unsigned)pass));
     };
-    auto end_of = [&](int item) { return chained ? min(p.first_sample + (pass_of(item) + 1) * p.chunk_spp, s_last) : s_last; };
+    auto begin_of = [&](int item) { const int ps = pass_of(item); return p.first_sample + (p.n_taper > 0 ? (ps > 0 ? (int)p.taper_end[ps - 1] : 0) : ps * p.chunk_spp); };
+    auto end_of = [&](int item) { return !chained ? s_last : p.n_taper > 0 ? p.first_sample + (int)p.taper_end[pass_of(item)] : min(p.first_sample + (pass_of(item) + 1) * p.chunk_spp, s_last); };
     // this lane's pixel of an item: LCG state, running mean, first sample
     // this lane's pixel of an item: LCG state, running mean, first sample.  A lane comes here on its own, a few at a time, so
     // what pixel_of_wave() and prog.cl:84-85 spend on integer divisions per lane is done on the scalar unit where the frame
@@ -338,7 +339,7 @@ PT_DEV void render_items_migrating(const RenderParams& p, const SceneView& sv, c
         if (camX != p.width) { const int gid = grow * p.width + x; gx = gid % camX; gy = gid / camX; }
         pxy = (unsigned)gx | ((unsigned)gy << 16);
         seed = p.rnds[li];
-        s = p.first_sample + pass_of(item) * p.chunk_spp;
+        s = begin_of(item);
         if (!LEAN) {
             acc = mk(0.0f, 0.0f, 0.0f);
             if (s != 0) {                          // prog.cl:312-314: sample 0 starts from black
@@ -501,7 +502,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
     for (int i = 0; i < 6; ++i) wc.low[i] = 0;
     const bool lane0 = (threadIdx.x & 63) == 0;
     const bool chained = p.tile_counter != nullptr && p.chunk_spp > 0;
-    const int n_pass = chained ? (p.nsamples + p.chunk_spp - 1) / p.chunk_spp : 1;
+    const int n_pass = chained ? (p.n_taper > 0 ? p.n_taper : (p.nsamples + p.chunk_spp - 1) / p.chunk_spp) : 1;
     // statistics of the launch: wave-level totals, kept in SCALAR registers (a per-lane 64-bit counter pair costs four VGPRs
     // through every traversal); a lane only counts the segments of its current work item, in 32 bits
     unsigned long long segs_tot = 0, samples_tot = 0, item_lane_steps = 0;
@@ -557,8 +558,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         }
-        const int s_begin = p.first_sample + (chained ? pass * p.chunk_spp : 0);
-        const int s_end = chained ? min(s_begin + p.chunk_spp, p.first_sample + p.nsamples) : p.first_sample + p.nsamples;
+        const bool tabled = chained && p.n_taper > 0;           // (passes of different lengths: RenderParams::taper_end)
+        const int s_begin = p.first_sample + (tabled ? (pass > 0 ? (int)p.taper_end[pass - 1] : 0) : chained ? pass * p.chunk_spp : 0);
+        const int s_end = tabled ? p.first_sample + (int)p.taper_end[pass] : chained ? min(s_begin + p.chunk_spp, p.first_sample + p.nsamples) : p.first_sample + p.nsamples;
         const PixelId px = pixel_of_wave(p, tile);
         unsigned item_segs = 0;
         const unsigned long long item_t0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;

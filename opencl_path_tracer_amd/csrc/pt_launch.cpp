@@ -169,6 +169,7 @@ void fill_params(const pt_context* ctx, const pt_camera* cam, RenderParams* p) {
     p->poll_ticks = (uint32_t)std::min<int64_t>((int64_t)ctx->poll_timeout_ms * 100000, 0xffffffffll);      // s_memrealtime: 100 MHz
     p->debug_stall_tile = ctx->debug_stall_tile;
     p->chunk_spp = 0;
+    p->n_taper = 0;
     p->tile_done = nullptr;
     p->n_tiles = ((ctx->W + 7) / 8) * ((ctx->local_rows + 7) / 8);
     // measured with the big-triangle list in place (profiles/r02/i_*): Cornell box in LDS 8 / 16 / 24 / 32 -> 1669 / 1690 /
@@ -272,11 +273,22 @@ static int ptamd_resident_waves(const pt_context*, const LaunchConfig& lc) { ret
 // Samples per (pass, tile) work item of a persistent launch, by tiles per resident wave (0: whole tiles).
 // fewer tiles per resident wave (1080p over 2 / 4 / 8 GPUs: 4.0 / 2.0 / 1.0): suspend with passes of 16, lockstep with
 // passes of 8, lockstep with whole tiles (profiles/r02/q_*: 95.7 % / 87.5 % / 61.8 % of the one-GPU rate per GPU)
-static int auto_chunk_spp(int n_tiles, int resident_waves, int nsamples, int schedule) {
-    if (schedule == 2) return nsamples >= 32 ? 8 : nsamples >= 8 ? 4 : 0;
+static int auto_chunk_spp(int n_tiles, int resident_waves, int nsamples, int schedule, int node_mode) {
+    // schedule 2 has no tail at the end of an item to amortise, so its items can be short where that re-balances the chip; what is
+    // left is the end of the LAUNCH, which auto_chunk_taper() shortens (profiles/r04/r_*, t_*)
+    if (schedule == 2) return node_mode == kNodesLds ? 32 : nsamples >= 32 ? 16 : nsamples >= 16 ? 8 : nsamples >= 8 ? 4 : 0;
     return n_tiles >= 5 * resident_waves ? (nsamples >= 256 ? 64 : 32)
          : n_tiles >= 3 * resident_waves ? 16
          : n_tiles > resident_waves + resident_waves / 4 ? 8 : 0;
+}
+// The shortest pass of a launch whose last chunk's worth of samples is cut in halves (64 samples in passes of 32 -> 32, 16, 8, 8): the
+// work counter hands items out pass by pass, so the launch ends on short items.  Only where short items cost nothing extra, i.e. under
+// schedule 2 (under schedule 1 every item ends on its slowest pixel: Cornell box 2,612 -> 2,557 / 2,584 / 2,605 with 2 / 4 / 8), and only
+// on launches long enough to have an end worth shortening (16 samples per launch: -1 ... -8 %).  64 samples per launch, schedule 2:
+// Cornell box 32 | 32,16,8,8 -> 2,568 | 2,684; MESH-100k 8 x 8 | 16 x 3, 8, 4, 4 -> 1,208 | 1,234; MESH-1M 460 | 468 (profiles/r04/t_*)
+static int auto_chunk_taper(int nsamples, int schedule, int node_mode) {
+    if (schedule != 2) return 0;
+    return node_mode == kNodesLds ? (nsamples >= 64 ? 8 : 0) : (nsamples >= 32 ? 4 : 0);
 }
 
 static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc) {
@@ -310,11 +322,12 @@ static void launch_cfg(pt_context* ctx, const RenderParams& p, LaunchConfig* lc)
     // ahead give up the coherence of a tile's camera rays -- lockstep up to 4 samples per launch with the tree in LDS
     // (render(1): 1,810 against 1,492 Msamples/s), for one sample otherwise (profiles/r03/q_*)
     const bool few_samples = p.nsamples <= (p.node_mode == kNodesLds ? 4 : 1);
-    // Round 4: where the restart schedule is taken AND the nodes come from global memory, its lanes also move on to the wave's next
-    // work item instead of waiting for the item's slowest pixel (schedule 2, render_items_migrating): MESH-100k 1,099 -> 1,190,
-    // MESH-1M 423 -> 456 Msamples/s at 64 samples per launch.  With the tree in LDS the same costs 1 % (2,646 -> 2,624: the VALU-bound
-    // instance pays for five more spilled dwords what it gains in lanes), so the Cornell box keeps schedule 1 (profiles/r04/r_*).
-    const int restart = (ctx->persistent && p.node_mode != kNodesLds) ? 2 : 1;
+    // Round 4: the restart schedule is the one whose lanes also move on to the wave's next work item instead of waiting for the item's
+    // slowest pixel (schedule 2, render_items_migrating): MESH-100k 1,099 -> 1,190, MESH-1M 423 -> 456 Msamples/s at 64 samples per
+    // launch.  The Cornell box gains nothing from that by itself (its lanes finish together: 2,646 -> 2,624) but, like the meshes, from
+    // the short last passes that only schedule 2 makes free (auto_chunk_taper: 2,613 -> 2,684, from 64 samples per launch; with 16
+    // schedule 1 leads 2,392 to 2,323) (profiles/r04/r_*, t_*).
+    const int restart = (ctx->persistent && (p.node_mode != kNodesLds || p.nsamples >= 64)) ? 2 : 1;
     lc->schedule = ctx->schedule >= 0 ? ctx->schedule : (!few_samples && p.n_tiles >= 3 * ptamd_resident_waves(ctx, *lc) ? restart : 0);
     ctx->last_lds_bytes = lc->lds_bytes;
     ctx->last_waves_per_simd = lc->waves_per_simd;
@@ -484,10 +497,29 @@ int pt_render(pt_context* ctx, const pt_camera* cam, int32_t iterations, int32_t
         const int resident_waves = ptamd_resident_waves(ctx, lc);
         // (schedule 2 has no tail at the end of an item to amortise: short passes, which re-balance the chip -- 4 / 8 / 16 / 32 samples per
         // item at 64 per launch: MESH-100k 1,138 / 1,190 / 1,186 / 1,146, MESH-1M 443 / 456 / 456 / 442; at 16 per launch 4 and 8 lead)
-        const int auto_chunk = auto_chunk_spp(p.n_tiles, resident_waves, nsamples, lc.schedule);
+        const int auto_chunk = auto_chunk_spp(p.n_tiles, resident_waves, nsamples, lc.schedule, p.node_mode);
         const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk;
         // work items are numbered with an int on the device: passes x tiles + one failed fetch per resident wave
-        const int64_t items = chunk > 0 ? ((int64_t)nsamples + chunk - 1) / chunk * p.n_tiles : p.n_tiles;
+        // passes of chunk samples, the last of them cut in halves down to `taper` samples: the launch ends on short items instead of
+        // on whole ones (the work counter hands items out pass by pass, so the short ones ARE the end of the launch)
+        int n_pass = chunk > 0 ? (int)(((int64_t)nsamples + chunk - 1) / chunk) : 1;
+        const int taper = ctx->chunk_taper >= 0 ? ctx->chunk_taper : auto_chunk_taper(nsamples, lc.schedule, p.node_mode);
+        if (chunk > 0 && nsamples > chunk && taper > 0 && taper < chunk && nsamples < 65536) {
+            std::vector<int> ends;
+            int done = 0;
+            while (nsamples - done > chunk) { done += chunk; ends.push_back(done); }
+            for (int left = nsamples - done; left > 0;) {
+                const int take = left >= 2 * taper ? left / 2 : left;
+                done += take;
+                left -= take;
+                ends.push_back(done);
+            }
+            if ((int)ends.size() <= kMaxTaperPasses) {
+                n_pass = p.n_taper = (int)ends.size();
+                for (int k = 0; k < n_pass; ++k) p.taper_end[k] = (uint16_t)ends[k];
+            }
+        }
+        const int64_t items = chunk > 0 ? (int64_t)n_pass * p.n_tiles : p.n_tiles;
         if (items + (int64_t)resident_waves + 64 >= ((int64_t)1 << 31))
             return fail(ctx, PT_EINVAL, "nsamples / chunk_spp x tiles does not fit the 31-bit work-item counter of one launch: render in several calls");
         if (chunk > 0 && nsamples > chunk && p.n_tiles > 0) {
@@ -555,7 +587,7 @@ int pt_debug_launch_plan(pt_context* ctx, int32_t nsamples, int32_t cu_count, in
     ctx->cu_count = saved_cu;
     ctx->last_lds_bytes = saved_lds;
     ctx->last_waves_per_simd = saved_wps;
-    const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk_spp(p.n_tiles, resident, nsamples, lc.schedule);
+    const int chunk = ctx->chunk_spp >= 0 ? ctx->chunk_spp : auto_chunk_spp(p.n_tiles, resident, nsamples, lc.schedule, p.node_mode);
     out[0] = lc.block; out[1] = lc.waves_per_simd; out[2] = lc.schedule; out[3] = (chunk > 0 && nsamples > chunk) ? chunk : 0;
     out[4] = resident; out[5] = p.n_tiles; out[6] = p.node_mode; out[7] = (int64_t)lc.lds_bytes;
     return PT_OK;

@@ -1367,3 +1367,22 @@ def test_lost_hand_over_under_the_migrating_schedule(api, cb_spec):
     sc.render(8)
     sc.sync()
     assert same_bits(sc.read_colors(), want_c) and np.array_equal(sc.read_rnds(), want_r)
+
+
+@pytest.mark.parametrize("schedule", [0, 1, 2])
+def test_tapered_passes(api, oracle, cb_spec, cb_oracle_scene, schedule):
+    """Option chunk_taper: the passes of a chained launch are chunk_spp samples long except the last chunk's worth, which is cut in
+    halves down to chunk_taper samples (13 samples in passes of 4 with taper 1: 4, 4, 4 -> 4, 4, 2, 1, 1, 1), so that the launch ends on
+    short work items.  Same frame as ever, under every schedule."""
+    W, H = 88, 64
+    fr, segs = oracle_render(oracle, cb_oracle_scene, cb_spec, W, H, 5, 13)
+    for chunk, taper in ((4, 1), (8, 2), (2, 1)):
+        sc = api.Scene(W, H).load(cb_spec)
+        sc.set_option("schedule", schedule)
+        sc.set_option("chunk_spp", chunk)
+        sc.set_option("chunk_taper", taper)
+        sc.iterations = 5
+        sc.render(13)
+        check(sc, fr, "schedule=%d chunk_spp=%d chunk_taper=%d" % (schedule, chunk, taper))
+        assert sc.stat("segments") == segs and sc.stat("samples") == W * H * 13
+        sc.close()

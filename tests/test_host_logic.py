@@ -295,8 +295,10 @@ def test_launch_plan_of_a_rank_of_eight(api, cb_spec):
         sc = api.Scene(W, H, device=None, rank=rank, world=world, rows_per_block=8).load(cb_spec)
         return sc.debug_launch_plan(nsamples, 256)
     one = plan(1920, 1080, 0, 1)
-    assert (one["block"], one["waves_per_simd"], one["schedule"], one["chunk_spp"]) == (768, 6, 1, 32) and one["tiles"] == 32400 and one["resident_waves"] == 6144
-    assert plan(1920, 1080, 0, 1, 256)["chunk_spp"] == 64
+    assert (one["block"], one["waves_per_simd"], one["schedule"], one["chunk_spp"]) == (768, 6, 2, 32) and one["tiles"] == 32400 and one["resident_waves"] == 6144
+    short = plan(1920, 1080, 0, 1, 16)         # short launches keep schedule 1 (no end worth tapering, and its lanes finish together)
+    assert short["schedule"] == 1, short
+    assert plan(1920, 1080, 0, 1, 256)["chunk_spp"] == 32
     for r in (0, 3, 7):
         p8 = plan(1920, 1080, r, 8)
         assert (p8["block"], p8["waves_per_simd"], p8["schedule"], p8["chunk_spp"]) == (512, 4, 0, 0), p8
@@ -311,8 +313,8 @@ def test_launch_plan_of_a_rank_of_eight(api, cb_spec):
     sc.set_option("lds_scene", 0)
     sc.load(cb_spec)
     m64, m16, m4 = sc.debug_launch_plan(64, 256), sc.debug_launch_plan(16, 256), sc.debug_launch_plan(4, 256)
-    assert (m64["block"], m64["waves_per_simd"], m64["schedule"], m64["chunk_spp"]) == (256, 7, 2, 8) and m64["node_mode"] != 0, m64
-    assert (m16["schedule"], m16["chunk_spp"]) == (2, 4) and (m4["schedule"], m4["chunk_spp"]) == (2, 0), (m16, m4)
+    assert (m64["block"], m64["waves_per_simd"], m64["schedule"], m64["chunk_spp"]) == (256, 7, 2, 16) and m64["node_mode"] != 0, m64
+    assert (m16["schedule"], m16["chunk_spp"]) == (2, 8) and (m4["schedule"], m4["chunk_spp"]) == (2, 0), (m16, m4)
 
 
 def test_device_policies_fall_back_to_the_tree_they_name(api):

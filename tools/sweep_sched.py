@@ -14,6 +14,7 @@ ap.add_argument("scenes")
 ap.add_argument("--sched", default="1,2")
 ap.add_argument("--chunk", default="-1")
 ap.add_argument("--ml", default="1")
+ap.add_argument("--taper", default="-1", help="chunk_taper values: shortest pass at the end of the launch (0 off)")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--opt", action="append", default=[], help="key=value set before the scene is loaded (lds_block=512, lds_scene=0 ...)")
 args = ap.parse_args()
@@ -32,17 +33,18 @@ for item in args.scenes.split(","):
     sc.set_option("timing", 1)
     sc.render(spp)
     sc.sync()
-    for sched, chunk, ml in itertools.product(ints(args.sched), ints(args.chunk), ints(args.ml)):
+    for sched, chunk, ml, taper in itertools.product(ints(args.sched), ints(args.chunk), ints(args.ml), ints(args.taper)):
         if sched != 2 and ml != ints(args.ml)[0]:
             continue
         sc.set_option("schedule", sched)
         sc.set_option("chunk_spp", chunk)
         sc.set_option("migrate_lanes", ml)
+        sc.set_option("chunk_taper", taper)
         sc.render(spp)
         sc.sync()
         sc.set_option("reset_stats", 1)
         for _ in range(args.reps):
             sc.render(spp)
         sc.sync()
-        print("%-9s spp %3d schedule %d chunk_spp %3d migrate_lanes %2d: %8.1f Msamples/s" % (name, spp, sched, chunk, ml, sc.stat("samples") / sc.stat("kernel_ms") / 1e3), flush=True)
+        print("%-9s spp %3d schedule %d chunk_spp %3d migrate_lanes %2d chunk_taper %2d: %8.1f Msamples/s" % (name, spp, sched, chunk, ml, taper, sc.stat("samples") / sc.stat("kernel_ms") / 1e3), flush=True)
     sc.close()
