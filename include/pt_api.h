@@ -196,9 +196,12 @@ int pt_set_stream(pt_context* ctx, void* hip_stream);                /* hipStrea
  *                  lanes of a wave start a sample together; 2 like 1, and a lane whose pixel has had its samples of the
  *                  wave's work item moves on to its pixel of the wave's next item instead of waiting for the item's
  *                  slowest pixel (persistent launches; "migrate_lanes": how many such lanes must have gathered, default 1);
- *                  -1 (default) by tiles per resident wave: from 3 (one or two GPUs at 1080p) 1 for a tree in LDS and
- *                  2 for nodes from global memory, else 0
+ *                  -1 (default) by tiles per resident wave: from 3 (one or two GPUs at 1080p) 2 -- for a tree in LDS only from
+ *                  64 samples per launch, below that 1 --, else 0
  *   "suspend_lanes" -1 (default: 16 for a tree in LDS, else 24), 0..63
+ *   "chunk_taper"  persistent launches with chained passes: > 0 the last "chunk_spp" samples of a launch are cut in halves down
+ *                  to this many (64 samples in passes of 32, taper 8: 32, 16, 8, 8), so that the launch ends on short work items;
+ *                  0 all passes "chunk_spp" long; -1 (default) 8 / 4 under schedule 2 from 64 / 32 samples per launch, else 0
  *   "lbvh_cluster" device-built trees (bvh_policy 4): the top of the tree above clusters of at most this many triangles is
  *                  rebuilt with the host's SAH over the cluster boxes (default 64; 0: the LBVH as the device built it);
  *                  set before the triangles are uploaded
