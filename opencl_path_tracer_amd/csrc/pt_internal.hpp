@@ -81,8 +81,11 @@ constexpr int kStatCols = 16;
 // that can be recomputed or fetched (LEAN, pt_kernels.hip) -- A/B switch: 8 = never.  7: at 80 VGPRs (six waves) the two
 // forms measure the same (2,347 / 2,354 on the Cornell box, 787 / 794 on MESH-100k, profiles/r03/r_*), and the plain one
 // leaves the frame buffer alone until the end of a pass.
+// Round 4: 6.  Under schedule 2 the plain 80-VGPR instance spills four registers of path state around every traversal -- stores in
+// the hot loop, whose dirty lines every agent-scope release of a chained pass writes back: 17.3 GB of WRITE_SIZE per 64-spp launch
+// of the Cornell box, against 4.0 GB for the lean form (whose frame-buffer lines are what is flushed), at +1 % (profiles/r04/u_*).
 #ifndef PT_LEAN_FROM_WPS
-#define PT_LEAN_FROM_WPS 7
+#define PT_LEAN_FROM_WPS 6
 #endif
 constexpr int kLeanFromWps = PT_LEAN_FROM_WPS;
 // The k_render instances for a tree staged whole in LDS (two workgroups per CU either way): 2 x 768 threads at an 80-VGPR
