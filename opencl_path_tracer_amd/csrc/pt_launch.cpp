@@ -286,7 +286,11 @@ static int auto_chunk_spp(int n_tiles, int resident_waves, int nsamples, int sch
 // schedule 2 (under schedule 1 every item ends on its slowest pixel: Cornell box 2,612 -> 2,557 / 2,584 / 2,605 with 2 / 4 / 8), and only
 // on launches long enough to have an end worth shortening (16 samples per launch: -1 ... -8 %).  64 samples per launch, schedule 2:
 // Cornell box 32 | 32,16,8,8 -> 2,568 | 2,684; MESH-100k 8 x 8 | 16 x 3, 8, 4, 4 -> 1,208 | 1,234; MESH-1M 460 | 468 (profiles/r04/t_*)
+// Lockstep items have no slowest pixel to end on either (the lanes of a wave finish a sample together), and the launches that run
+// lockstep with chained passes -- the tile sets of ranks of 2 / 4, two to four tiles per resident wave -- are the ones whose end
+// weighs most: passes of 8 ... 8, 4, 2, 2 instead of 8 x 8: a rank of 2 4,223 -> 4,294, a rank of 4 6,733 -> 6,881 Msamples/s whole job.
 static int auto_chunk_taper(int nsamples, int schedule, int node_mode) {
+    if (schedule == 0) return nsamples >= 32 ? 2 : 0;
     if (schedule != 2) return 0;
     return node_mode == kNodesLds ? (nsamples >= 64 ? 8 : 0) : (nsamples >= 32 ? 4 : 0);
 }
