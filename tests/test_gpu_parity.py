@@ -1386,3 +1386,45 @@ def test_tapered_passes(api, oracle, cb_spec, cb_oracle_scene, schedule):
         check(sc, fr, "schedule=%d chunk_spp=%d chunk_taper=%d" % (schedule, chunk, taper))
         assert sc.stat("segments") == segs and sc.stat("samples") == W * H * 13
         sc.close()
+
+
+def test_migrating_schedule_full_size_stress(api, cb_spec):
+    """Schedule 2 under real concurrency: 1920x1080, 8 bounces, 12 samples as chained passes of one and of three samples (388,800 and
+    129,600 hand-overs, every wave with two work items in hand most of the time), with the tree in LDS and with nodes from global memory,
+    and a small frame whose 64 tiles are fought over by every wave of the grid in 40 single-sample passes -- the same bits as one
+    unchained launch under schedule 1, every time (timing differs from run to run)."""
+    W, H = 1920, 1080
+    for lds in (2, 0):
+        a = api.Scene(W, H)
+        a.set_option("lds_scene", lds)
+        a.load(cb_spec)
+        a.set_option("schedule", 1)
+        a.set_option("chunk_spp", 0)
+        a.iterations = 8
+        a.render(12)
+        ca, ra = a.read_colors(), a.read_rnds()
+        a.close()
+        for chunk, taper in ((1, 0), (3, 1), (1, 0)):
+            b = api.Scene(W, H)
+            b.set_option("lds_scene", lds)
+            b.load(cb_spec)
+            b.set_option("schedule", 2)
+            b.set_option("chunk_spp", chunk)
+            b.set_option("chunk_taper", taper)
+            b.iterations = 8
+            b.render(12)
+            assert same_bits(ca, b.read_colors()) and np.array_equal(ra, b.read_rnds()), (lds, chunk, taper)
+            b.close()
+    a = api.Scene(64, 64).load(cb_spec)
+    a.set_option("schedule", 0)
+    a.iterations = 6
+    a.render(40)
+    ca, ra = a.read_colors(), a.read_rnds()
+    for _ in range(3):
+        b = api.Scene(64, 64).load(cb_spec)
+        b.set_option("schedule", 2)
+        b.set_option("chunk_spp", 1)
+        b.iterations = 6
+        b.render(40)
+        assert same_bits(ca, b.read_colors()) and np.array_equal(ra, b.read_rnds())
+        b.close()
