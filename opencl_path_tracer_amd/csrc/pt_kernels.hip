@@ -227,6 +227,38 @@ PT_DEV void render_pixel_suspend(const RenderParams& p, const SceneView& sv, con
     }
 }
 
+// Chained passes: wait until pass `pass` - 1 of `tile` has been released (tile_done[tile] >= pass).  The producer was dequeued earlier
+// by a resident wave, so the wait ends -- unless that wave died (a fault in its item) or the launch is already winding down.  The poll
+// is therefore BOUNDED: after poll_ticks (10 s by default) the wave reports the tile in tile_counter[kTileCounterError] and gives up;
+// every other waiting wave sees that word and gives up too, the launch drains, and the host turns the word into PT_EHIP (pt_sync)
+// instead of a hung process.  Returns 1 when the hand-over came, 0 when it was lost (here or elsewhere).  Wave-uniform throughout.
+PT_DEV int wait_tile_pass(const RenderParams& p, int tile, int pass, bool lane0) {
+    unsigned seen = 0, lost = 0, polls = 0;
+    const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (lane0) seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+        if (seen >= (unsigned)pass) break;
+        // now and then (every 64th poll: thousands of waves poll at once, and one word read by all of them every
+        // microsecond is a hot spot of its own): has another wave given up, or is it time to?
+        if ((++polls & 63u) == 0) {
+            if (lane0) lost = __hip_atomic_load(&p.tile_counter[kTileCounterError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lost = (unsigned)__builtin_amdgcn_readfirstlane((int)lost);
+            if (lost != 0) break;
+            if (__builtin_amdgcn_s_memrealtime() - w0 > (unsigned long long)p.poll_ticks) {
+                // (tile and pass in ONE 8-byte compare-and-swap: the first wave to give up names them)
+                const unsigned long long mine = ((unsigned long long)(unsigned)pass << 32) | (unsigned long long)((unsigned)tile + 1u);
+                unsigned long long was = 0;
+                if (lane0) was = atomicCAS(reinterpret_cast<unsigned long long*>(&p.tile_counter[kTileCounterError]), 0ull, mine);
+                (void)__builtin_amdgcn_readfirstlane((int)(unsigned)was);
+                break;
+            }
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return __builtin_amdgcn_readfirstlane((int)(seen >= (unsigned)pass));
+}
+
 // kSchedMigrate: the whole item loop of a persistent launch (p.tile_counter != 0), chained passes or whole tiles.
 //
 // Wave-uniform: the current item (cur_*) and, once a lane has finished its pixel of it, the next one (nxt_*), fetched from the work
@@ -289,32 +321,9 @@ PT_DEV void render_items_migrating(const RenderParams& p, const SceneView& sv, c
         seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
         return __builtin_amdgcn_readfirstlane((int)(seen >= (unsigned)pass));
     };
-    // the bounded wait of k_render: 1 when the hand-over came, 0 when it was lost (here or elsewhere)
-    auto wait_released = [&](int item) {
-        const int pass = pass_of(item), tile = tile_of(item);
-        if (pass == 0) return 1;
-        unsigned seen = 0, lost = 0, polls = 0;
-        const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-            if (lane0) seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
-            if (seen >= (unsigned)pass) break;
-            if ((++polls & 63u) == 0) {
-                if (lane0) lost = __hip_atomic_load(&p.tile_counter[kTileCounterError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lost = (unsigned)__builtin_amdgcn_readfirstlane((int)lost);
-                if (lost != 0) break;
-                if (__builtin_amdgcn_s_memrealtime() - w0 > (unsigned long long)p.poll_ticks) {
-                    const unsigned long long mine = ((unsigned long long)(unsigned)pass << 32) | (unsigned long long)((unsigned)tile + 1u);
-                    unsigned long long was = 0;
-                    if (lane0) was = atomicCAS(reinterpret_cast<unsigned long long*>(&p.tile_counter[kTileCounterError]), 0ull, mine);
-                    const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)was);
-                    lost = first != 0 ? first : (unsigned)tile + 1u;
-                    break;
-                }
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        return __builtin_amdgcn_readfirstlane((int)(seen >= (unsigned)pass));
+    auto wait_released = [&](int item) {       // ... or wait for it (bounded: wait_tile_pass)
+        const int pass = pass_of(item);
+        return pass == 0 ? 1 : wait_tile_pass(p, tile_of(item), pass, lane0);
     };
     auto begin_of = [&](int item) { const int ps = pass_of(item); return p.first_sample + (p.n_taper > 0 ? (ps > 0 ? (int)p.taper_end[ps - 1] : 0) : ps * p.chunk_spp); };
     auto end_of = [&](int item) { return !chained ? s_last : p.n_taper > 0 ? p.first_sample + (int)p.taper_end[pass_of(item)] : min(p.first_sample + (pass_of(item) + 1) * p.chunk_spp, s_last); };
@@ -526,35 +535,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_render(RenderParams p) {
             tile = t - pass * p.n_tiles;
             if (chained ? pass >= n_pass : tile >= p.n_tiles) break;
             if (pass > 0) {                                      // ---- acquire the tile's previous pass
-                // The producer was dequeued earlier by a resident wave, so the wait ends -- unless that wave died (a fault in its
-                // item) or the launch is already winding down.  The poll is therefore BOUNDED: after poll_ticks (2 s by default) the
-                // wave reports the tile in tile_counter[kTileCounterError] and leaves; every other waiting wave sees that word and
-                // leaves too, the launch drains, and the host turns the word into PT_EHIP (pt_sync) instead of a hung process.
-                unsigned seen = 0, lost = 0, polls = 0;
-                const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
-                for (;;) {
-                    if (lane0) seen = __hip_atomic_load(&p.tile_done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
-                    if (seen >= (unsigned)pass) break;
-                    // now and then (every 64th poll: thousands of waves poll at once, and one word read by all of them every
-                    // microsecond is a hot spot of its own): has another wave given up, or is it time to?
-                    if ((++polls & 63u) == 0) {
-                        if (lane0) lost = __hip_atomic_load(&p.tile_counter[kTileCounterError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        lost = (unsigned)__builtin_amdgcn_readfirstlane((int)lost);
-                        if (lost != 0) break;
-                        if (__builtin_amdgcn_s_memrealtime() - w0 > (unsigned long long)p.poll_ticks) {
-                            // (tile and pass in ONE 8-byte compare-and-swap: the first wave to give up names them)
-                            const unsigned long long mine = ((unsigned long long)(unsigned)pass << 32) | (unsigned long long)((unsigned)tile + 1u);
-                            unsigned long long was = 0;
-                            if (lane0) was = atomicCAS(reinterpret_cast<unsigned long long*>(&p.tile_counter[kTileCounterError]), 0ull, mine);
-                            const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)was);
-                            lost = first != 0 ? first : (unsigned)tile + 1u;
-                            break;
-                        }
-                    }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                if (seen < (unsigned)pass) break;                // a hand-over was lost somewhere: this wave renders nothing more
+                if (!wait_tile_pass(p, tile, pass, lane0)) break;   // a hand-over was lost somewhere: this wave renders nothing more
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         }
