@@ -234,10 +234,10 @@ def all_configs(device):
     work = tempfile.mkdtemp(prefix="ptamd_bench_")
     try:
         return [
-            run_config("config 1", "Cornell box, 256x256, 4 bounces, 16 spp per step (the reference CPU path's config: 16 spp in all)", lambda: api.Scene(256, 256, device=device).load(cb()), 256, 256, 4, 16, 16, None),
+            run_config("config 1", "Cornell box, 256x256, 4 bounces, 16 spp per step (the reference CPU path's config: 16 spp in all)", lambda: api.Scene(256, 256, device=device).load(cb()), 256, 256, 4, 16, 16, "cornell"),
             run_config("config 3", "MESH-100k (OBJ+MTL through pt_add_obj, 100,352 + 12 triangles), 1920x1080, 8 bounces, 64 spp per step",
                        lambda: mesh_scene_through_add_obj(100000, 1920, 1080, device, work), 1920, 1080, 8, 64, 2, "mesh100k"),
-            run_config("config 4 at N=1", "Cornell box, 3840x2160, 8 bounces, 16 spp per step", lambda: api.Scene(3840, 2160, device=device).load(cb()), 3840, 2160, 8, 16, 3, None),
+            run_config("config 4 at N=1", "Cornell box, 3840x2160, 8 bounces, 16 spp per step", lambda: api.Scene(3840, 2160, device=device).load(cb()), 3840, 2160, 8, 16, 3, "cornell"),
             run_config("config 5", "MESH-1M (OBJ+MTL through pt_add_obj, 1,002,528 + 12 triangles), 1920x1080, 16 bounces, 64 spp per step",
                        lambda: mesh_scene_through_add_obj(1000000, 1920, 1080, device, work), 1920, 1080, 16, 64, 2, "mesh1m"),
         ]

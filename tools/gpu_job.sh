@@ -3,7 +3,7 @@
 #   tests  the GPU test suite (-m gpu), log under gpurun_out/<tag>/tests.log
 #   abtests <lib> <-k expr>   GPU tests matching the expression against an A/B library
 #   bench  bench.py, then bench.py --steps 5 under rocprofv3 --kernel-trace --stats
-#   pmc    the rocprofv3 --pmc passes of the four tracked launch shapes -> gpurun_out/counters.json (copy it to profiles/)
+#   pmc    the rocprofv3 --pmc passes of the six tracked launch shapes -> gpurun_out/counters.json (copy it to profiles/)
 #   sweep  tools/sweep.py --count on every BASELINE config
 #   ab     mesh / Cornell rates with the default library and with every A/B library named (make ab AB=...)
 # Everything is written under gpurun_out/<tag>/.
@@ -33,6 +33,8 @@ while [ $# -gt 0 ]; do
         tools/pmc_passes.sh ${tag}_cb scene=cornell spp=64 reps=2 > $out/pmc_cb.log 2>&1 && python3 tools/pmc_record.py cornell_1920x1080_b8_spp64 gpurun_out/counters.json gpurun_out/pmc_${tag}_cb_[0-9] > $out/pmc_cb_record.log 2>&1; tail -24 $out/pmc_cb_record.log
         tools/pmc_passes.sh ${tag}_mesh100k scene=mesh100k spp=64 reps=2 > $out/pmc_mesh100k.log 2>&1 && python3 tools/pmc_record.py mesh100k_1920x1080_b8_spp64 gpurun_out/counters.json gpurun_out/pmc_${tag}_mesh100k_[0-9] > $out/pmc_mesh100k_record.log 2>&1; tail -24 $out/pmc_mesh100k_record.log
         tools/pmc_passes.sh ${tag}_mesh1m scene=mesh1m spp=64 bounces=16 reps=2 > $out/pmc_mesh1m.log 2>&1 && python3 tools/pmc_record.py mesh1m_1920x1080_b16_spp64 gpurun_out/counters.json gpurun_out/pmc_${tag}_mesh1m_[0-9] > $out/pmc_mesh1m_record.log 2>&1; tail -24 $out/pmc_mesh1m_record.log
+        tools/pmc_passes.sh ${tag}_c1 scene=cornell W=256 H=256 bounces=4 spp=16 reps=8 > $out/pmc_c1.log 2>&1 && python3 tools/pmc_record.py cornell_256x256_b4_spp16 gpurun_out/counters.json gpurun_out/pmc_${tag}_c1_[0-9] > $out/pmc_c1_record.log 2>&1; tail -6 $out/pmc_c1_record.log
+        tools/pmc_passes.sh ${tag}_c4 scene=cornell W=3840 H=2160 spp=16 reps=2 > $out/pmc_c4.log 2>&1 && python3 tools/pmc_record.py cornell_3840x2160_b8_spp16 gpurun_out/counters.json gpurun_out/pmc_${tag}_c4_[0-9] > $out/pmc_c4_record.log 2>&1; tail -6 $out/pmc_c4_record.log
         tools/pmc_passes.sh ${tag}_wf scene=cornell spp=4 reps=2 variant=1 wf_streams=1 > $out/pmc_wf.log 2>&1 && python3 tools/pmc_record.py wavefront_cornell_1920x1080_b8_spp1 gpurun_out/counters.json gpurun_out/pmc_${tag}_wf_[0-9] > $out/pmc_wf_record.log 2>&1; tail -24 $out/pmc_wf_record.log;;
     sweep) timeout -k 10 600 python tools/sweep.py --count --what cb,c1c4,mesh100k,mesh1m > $out/sweep_all.txt 2>&1; grep -v "^$" $out/sweep_all.txt | cut -c1-330;;
   esac
